@@ -1,0 +1,156 @@
+/*
+ * mrc_hip.h -- C ABI of libmrc_hip.so: the MI355X (gfx950) implementation of the per-block ENCODE
+ * hot path of laser55/mrcAudioCodec (KBD/transition window -> MDCT -> FFT psychoacoustic masked
+ * threshold / SMR -> greedy bit allocation -> scale-factor / mantissa quantise -> per-band M/S).
+ *
+ * The reference has no FFI of its own: its plugin seam is the Python module `codecThem`
+ * (pacfileThem.py:108 `import codecThem as codec`; calls at pacfileThem.py:649 -> 987-994 and
+ * 820 -> 996-1003).  The entry points below are what a binding for that seam needs; the drop-in
+ * Python module mrcaudiocodec_amd/codecThem.py binds them with ctypes.
+ *
+ * Conventions: every function returns 0 on success, a negative mrc_status on error
+ * (mrc_last_error(h) gives the text); no exceptions cross the ABI; a handle is bound to one HIP
+ * device and calls on one handle must be serialised by the caller.  There is NO CPU fallback: if
+ * no gfx950 device is usable, mrc_create fails with MRC_ERR_NO_DEVICE.
+ * "host" functions take host pointers (C-contiguous, caller-allocated outputs) and copy for the
+ * caller; "dev" functions take device pointers (HIP allocations of the handle's device) and enqueue
+ * on the given hipStream_t (passed as void*; NULL = the handle's own stream) without synchronising.
+ *
+ * Block shapes.  A block is `a` samples carried over from the previous call followed by `b` new
+ * samples (pacfileThem.py:628-631), N = a+b, N/2 MDCT lines.  With nMDCTLines = 1024 and
+ * nSamplesShort = 128 the shapes are (1024,1024) long / 25 bands, (128,128) short / 9 bands and the
+ * two transitions (1024,128), (128,1024) with 576 lines / 9 bands (pacfileThem.py:637-645,1192-1210).
+ *
+ * Dense output layout (per block): overall_scale[nsig], scale_factor[nstream][nBands],
+ * bit_alloc[nstream][nBands], mantissa[nstream][N/2] (0 where the band got no bits; the reference
+ * omits those bands, codecThem.py:336-350 -- the Python wrapper compacts), reservoir_out.
+ * mono: nsig = nstream = 1.  joint stereo: nsig = 4 in the order L,R,M,S (codecThem.py:456-460),
+ * nstream = 2 (stream 0 = Mid-or-Left per band, stream 1 = Side-or-Right, codecThem.py:524-551),
+ * plus ms_switch[nBands].
+ */
+#ifndef MRC_HIP_H
+#define MRC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRC_VERSION 100            /* 0.1.0 */
+#define MRC_MAX_BANDS 32
+
+typedef enum mrc_status {
+    MRC_OK = 0,
+    MRC_ERR_INVALID = -1,          /* bad argument (shape, sizes, null pointer) */
+    MRC_ERR_NO_DEVICE = -2,        /* no usable HIP device / not gfx950 */
+    MRC_ERR_HIP = -3,              /* a HIP runtime call failed */
+    MRC_ERR_NOMEM = -4
+} mrc_status;
+
+/* The codec parameters the path reads from the reference's CodingParams bag
+ * (audiofile.py:51-53; values set at pacfileThem.py:1105-1121). */
+typedef struct mrc_config {
+    int32_t sample_rate;           /* codingParams.sampleRate (integer Hz: py2 `sampleRate/N` is an int division) */
+    int32_t n_mdct_lines;          /* codingParams.nMDCTLines, 1024 */
+    int32_t n_short;               /* codingParams.nSamplesShort, 128 */
+    int32_t n_scale_bits;          /* codingParams.nScaleBits, 4 */
+    int32_t n_mant_size_bits;      /* codingParams.nMantSizeBits, 4 */
+    int32_t blksw_bits_a;          /* codingParams.blkswBitA, 1 */
+    int32_t blksw_bits_b;          /* codingParams.blkswBitB, 1 */
+    int32_t device_id;             /* HIP device ordinal */
+    double  target_bits_per_sample;/* codingParams.targetBitsPerSample, 2.86 */
+} mrc_config;
+
+typedef struct mrc_handle mrc_handle;
+
+int  mrc_version(void);
+int  mrc_device_count(void);                              /* number of HIP devices, 0 if none */
+void mrc_default_config(mrc_config* cfg);                 /* pacfileThem.py:1105-1121 defaults, 48 kHz, device 0 */
+int  mrc_create(const mrc_config* cfg, mrc_handle** out);
+void mrc_destroy(mrc_handle* h);
+const char* mrc_last_error(const mrc_handle* h);          /* h may be NULL: error of the last failed mrc_create */
+
+/* Shape queries (band tables of psychoac.py:86-131 / pacfileThem.py:637-645). */
+int  mrc_shape_bands(mrc_handle* h, int a, int b, int32_t* n_bands, int32_t* n_lines /*[MRC_MAX_BANDS]*/);
+int  mrc_shape_budget(mrc_handle* h, int a, int b, int joint, int32_t reservoir, double* bit_budget);
+
+/* ---- host entry points: what codecThem.EncodeSingleChannel / JointEncodeChannels bind ---------- */
+
+/* codecThem.py:281-354 for n_blocks independent blocks of one shape.  blocks: [n_blocks][a+b].
+ * reservoir_in may be NULL (zeros).  mdct_out (unscaled lines, [n_blocks][N/2]) may be NULL. */
+int mrc_encode_mono(mrc_handle* h, int64_t n_blocks, int a, int b, const double* blocks,
+                    const int32_t* reservoir_in,
+                    int32_t* overall_scale, int32_t* scale_factor, int32_t* bit_alloc,
+                    int32_t* mantissa, int32_t* reservoir_out, double* mdct_out);
+
+/* codecThem.py:359-574.  left/right: [n_blocks][a+b].  overall_scale: [n_blocks][4] (L,R,M,S);
+ * ms_switch: [n_blocks][nBands]; scale_factor/bit_alloc: [n_blocks][2][nBands];
+ * mantissa: [n_blocks][2][N/2]; mdct_out: [n_blocks][4][N/2] or NULL. */
+int mrc_encode_joint(mrc_handle* h, int64_t n_blocks, int a, int b, const double* left, const double* right,
+                     const int32_t* reservoir_in,
+                     int32_t* overall_scale, int32_t* ms_switch, int32_t* scale_factor, int32_t* bit_alloc,
+                     int32_t* mantissa, int32_t* reservoir_out, double* mdct_out);
+
+/* ---- stage-level host entry points (parity tests against the reference's own modules) ---------- */
+
+/* window.py:104-121 (TransitionWindow; KBDWindow when a == b): out[n_blocks][a+b] = blocks * window. */
+int mrc_window(mrc_handle* h, int64_t n_blocks, int a, int b, const double* blocks, double* out);
+/* mdct.py:63-76 (+ window.py:104-121 when apply_window != 0) + codecThem.py:321-322: MDCT lines
+ * (unscaled, [n_blocks][N/2]) and overall scale of each block. */
+int mrc_mdct(mrc_handle* h, int64_t n_blocks, int a, int b, const double* blocks, int apply_window,
+             double* lines, int32_t* overall_scale);
+/* psychoac.py:176-219 (CalcSMRs): smr[n_blocks][nBands]; thresh (masked threshold,
+ * psychoac.py:134-173, [n_blocks][N/2]) may be NULL.  scaled_lines [n_blocks][N/2] are the MDCT lines
+ * already multiplied by 2^overall_scale[i] as CalcSMRs receives them; pass scaled_lines = NULL (and
+ * overall_scale = NULL) to have them computed from `blocks` by the windowed MDCT. */
+int mrc_smr(mrc_handle* h, int64_t n_blocks, int a, int b, const double* blocks,
+            const double* scaled_lines, const int32_t* overall_scale, double* smr, double* thresh);
+/* bitalloc.py:106-155 for n_cases independent problems of n_bands (<= 64) bands each:
+ * smr [n_cases][n_bands] (not modified), n_lines [n_bands], budget [n_cases].
+ * bits [n_cases][n_bands], bits_left [n_cases] (int(bitsLeft), truncated toward zero). */
+int mrc_bitalloc(mrc_handle* h, int64_t n_cases, int n_bands, int max_mant_bits, const int32_t* n_lines,
+                 const double* budget, const double* smr, int32_t* bits, int32_t* bits_left);
+/* quantize.py:114-146 elementwise: scale[i] = ScaleFactor(v[i], n_scale_bits, n_mant_bits[i]). */
+int mrc_scale_factor(mrc_handle* h, int64_t n, int n_scale_bits, const double* v, const int32_t* n_mant_bits,
+                     int32_t* scale);
+/* quantize.py:294-322 elementwise: mant[i] = vMantissa([x[i]], scale[i], n_scale_bits, n_mant_bits[i]). */
+int mrc_mantissa(mrc_handle* h, int64_t n, int n_scale_bits, const double* x, const int32_t* scale,
+                 const int32_t* n_mant_bits, int32_t* mant);
+/* ms_stereo.py:5-27 for n_blocks pairs of line vectors [n_blocks][n_total_lines] and one band table. */
+int mrc_ms_switch(mrc_handle* h, int64_t n_blocks, int n_bands, const int32_t* n_lines,
+                  const double* lines_left, const double* lines_right, int32_t* ms_switch);
+
+/* ---- device entry points (batch / stream mode; what bench.py and multi-GPU sharding drive) ------ */
+
+/* Frame f of the batch reads its a+b samples at ch[offsets ? offsets[f] : f*frame_stride ...].
+ * frame_stride = b  -> an overlapped PCM stream, every hop read once (pacfileThem.py:628-631);
+ * frame_stride = a+b -> explicit blocks.  ch_right == NULL -> mono (nsig = 1), else joint (nsig = 4).
+ * Buffers (device): lines [n][nsig][N/2] f64, overall_scale [n][nsig] i32, smr [n][nsig][nBands] f64,
+ * ms_switch [n][nBands] i32 (joint only), bit_alloc/scale_factor [n][nstream][nBands] i32,
+ * mantissa [n][nstream][N/2] i32, reservoir_in (may be NULL) / reservoir_out [n] i32. */
+int mrc_dev_mdct(mrc_handle* h, int a, int b, int64_t n_frames, const double* ch_left, const double* ch_right,
+                 int64_t frame_stride, const int64_t* offsets, double* lines, int32_t* overall_scale, void* stream);
+int mrc_dev_smr(mrc_handle* h, int a, int b, int64_t n_frames, const double* ch_left, const double* ch_right,
+                int64_t frame_stride, const int64_t* offsets, const double* lines, const int32_t* overall_scale,
+                double* smr, double* thresh /*nullable*/, void* stream);
+int mrc_dev_alloc_quant(mrc_handle* h, int a, int b, int64_t n_frames, int joint,
+                        const double* lines, const int32_t* overall_scale, const double* smr,
+                        const int32_t* reservoir_in, int32_t* ms_switch, int32_t* bit_alloc,
+                        int32_t* scale_factor, int32_t* mantissa, int32_t* reservoir_out, void* stream);
+/* The three stages back to back, intermediates in the handle's workspace (grown on demand, never
+ * inside a timed loop once warm).  lines_out may be NULL. */
+int mrc_dev_encode(mrc_handle* h, int a, int b, int64_t n_frames, const double* ch_left, const double* ch_right,
+                   int64_t frame_stride, const int64_t* offsets, const int32_t* reservoir_in,
+                   int32_t* overall_scale, int32_t* ms_switch, int32_t* bit_alloc, int32_t* scale_factor,
+                   int32_t* mantissa, int32_t* reservoir_out, double* lines_out, void* stream);
+
+/* Per-stage device time of the most recent mrc_dev_encode / stage call when timing is enabled
+ * (hipEvents on the launch stream; the call then synchronises).  ms[0..2] = mdct, smr, alloc+quant. */
+int mrc_set_timing(mrc_handle* h, int enabled);
+int mrc_get_stage_ms(mrc_handle* h, double* ms /*[3]*/);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRC_HIP_H */

@@ -1,0 +1,279 @@
+"""
+ctypes binding of libmrc_hip.so (include/mrc_hip.h).  Thin: argument marshalling and error mapping
+only.  There is no fallback of any kind: if the shared library is missing the import fails, and if no
+gfx950 device is usable `Handle()` raises -- nothing in this package computes on the CPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmrc_hip.so")
+
+MRC_MAX_BANDS = 32
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_f64p = C.POINTER(C.c_double)
+
+
+class MrcConfig(C.Structure):
+    _fields_ = [("sample_rate", C.c_int32), ("n_mdct_lines", C.c_int32), ("n_short", C.c_int32),
+                ("n_scale_bits", C.c_int32), ("n_mant_size_bits", C.c_int32), ("blksw_bits_a", C.c_int32),
+                ("blksw_bits_b", C.c_int32), ("device_id", C.c_int32), ("target_bits_per_sample", C.c_double)]
+
+
+class MrcError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "mrcaudiocodec_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C mrcaudiocodec_amd/csrc` (hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    sig = {
+        "mrc_version": (C.c_int, []),
+        "mrc_device_count": (C.c_int, []),
+        "mrc_default_config": (None, [C.POINTER(MrcConfig)]),
+        "mrc_create": (C.c_int, [C.POINTER(MrcConfig), C.POINTER(H)]),
+        "mrc_destroy": (None, [H]),
+        "mrc_last_error": (C.c_char_p, [H]),
+        "mrc_shape_bands": (C.c_int, [H, C.c_int, C.c_int, _i32p, _i32p]),
+        "mrc_shape_budget": (C.c_int, [H, C.c_int, C.c_int, C.c_int, C.c_int32, _f64p]),
+        "mrc_encode_mono": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, _f64p, _i32p, _i32p, _i32p, _i32p, _i32p,
+                                      _i32p, _f64p]),
+        "mrc_encode_joint": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, _f64p, _f64p, _i32p, _i32p, _i32p, _i32p,
+                                       _i32p, _i32p, _i32p, _f64p]),
+        "mrc_window": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, _f64p, _f64p]),
+        "mrc_mdct": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, _f64p, C.c_int, _f64p, _i32p]),
+        "mrc_smr": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, _f64p, _f64p, _i32p, _f64p, _f64p]),
+        "mrc_bitalloc": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, _i32p, _f64p, _f64p, _i32p, _i32p]),
+        "mrc_scale_factor": (C.c_int, [H, C.c_int64, C.c_int, _f64p, _i32p, _i32p]),
+        "mrc_mantissa": (C.c_int, [H, C.c_int64, C.c_int, _f64p, _i32p, _i32p, _i32p]),
+        "mrc_ms_switch": (C.c_int, [H, C.c_int64, C.c_int, _i32p, _f64p, _f64p, _i32p]),
+        "mrc_dev_mdct": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                   C.c_void_p, C.c_void_p, C.c_void_p]),
+        "mrc_dev_smr": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+        "mrc_dev_alloc_quant": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_int] + [C.c_void_p] * 10),
+        "mrc_dev_encode": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64] +
+                           [C.c_void_p] * 10),
+        "mrc_set_timing": (C.c_int, [H, C.c_int]),
+        "mrc_get_stage_ms": (C.c_int, [H, _f64p]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here = the library does not export the header's symbol
+        fn.restype = res
+        fn.argtypes = args
+    return lib, tuple(sig)
+
+
+lib, EXPORTS = _load()
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a, typ):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+class Handle:
+    """One mrc_handle: a device, a stream, the constant tables of the block shapes."""
+
+    def __init__(self, sample_rate=48000, n_mdct_lines=1024, n_short=128, n_scale_bits=4, n_mant_size_bits=4,
+                 target_bits_per_sample=2.86, blksw_bits_a=1, blksw_bits_b=1, device_id=0):
+        cfg = MrcConfig()
+        lib.mrc_default_config(C.byref(cfg))
+        cfg.sample_rate = int(sample_rate)
+        cfg.n_mdct_lines = int(n_mdct_lines)
+        cfg.n_short = int(n_short)
+        cfg.n_scale_bits = int(n_scale_bits)
+        cfg.n_mant_size_bits = int(n_mant_size_bits)
+        cfg.target_bits_per_sample = float(target_bits_per_sample)
+        cfg.blksw_bits_a = int(blksw_bits_a)
+        cfg.blksw_bits_b = int(blksw_bits_b)
+        cfg.device_id = int(device_id)
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        rc = lib.mrc_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            msg = lib.mrc_last_error(None)
+            self._h = None
+            raise MrcError("mrc_create failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+        self._bands = {}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib.mrc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = lib.mrc_last_error(self._h)
+            raise MrcError("libmrc_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+
+    # ---- shape queries
+    def bands(self, a, b):
+        """nLines per scale-factor band of shape (a,b) (int32 array)."""
+        key = (int(a), int(b))
+        if key not in self._bands:
+            n = C.c_int32()
+            buf = np.zeros(MRC_MAX_BANDS, dtype=np.int32)
+            self._check(lib.mrc_shape_bands(self._h, key[0], key[1], C.byref(n), _p(buf, _i32p)))
+            self._bands[key] = buf[:n.value].copy()
+        return self._bands[key]
+
+    def budget(self, a, b, joint, reservoir=0):
+        v = C.c_double()
+        self._check(lib.mrc_shape_budget(self._h, int(a), int(b), int(bool(joint)), int(reservoir), C.byref(v)))
+        return v.value
+
+    # ---- host entry points
+    def encode_mono(self, blocks, a, b, reservoir_in=None, want_mdct=False):
+        blocks = _f64(blocks)
+        n, N = blocks.shape
+        if N != a + b:
+            raise ValueError("blocks must be [n][a+b]")
+        nb, half = len(self.bands(a, b)), N // 2
+        res_in = None if reservoir_in is None else _i32(reservoir_in)
+        out = dict(overall_scale=np.empty(n, np.int32), scale_factor=np.empty((n, nb), np.int32),
+                   bit_alloc=np.empty((n, nb), np.int32), mantissa=np.empty((n, half), np.int32),
+                   reservoir_out=np.empty(n, np.int32))
+        mdct = np.empty((n, half), np.float64) if want_mdct else None
+        self._check(lib.mrc_encode_mono(self._h, n, a, b, _p(blocks, _f64p), _p(res_in, _i32p),
+                                        _p(out["overall_scale"], _i32p), _p(out["scale_factor"], _i32p),
+                                        _p(out["bit_alloc"], _i32p), _p(out["mantissa"], _i32p),
+                                        _p(out["reservoir_out"], _i32p), _p(mdct, _f64p)))
+        if want_mdct:
+            out["mdct"] = mdct
+        return out
+
+    def encode_joint(self, left, right, a, b, reservoir_in=None, want_mdct=False):
+        left, right = _f64(left), _f64(right)
+        n, N = left.shape
+        if N != a + b or right.shape != left.shape:
+            raise ValueError("left/right must be [n][a+b]")
+        nb, half = len(self.bands(a, b)), N // 2
+        res_in = None if reservoir_in is None else _i32(reservoir_in)
+        out = dict(overall_scale=np.empty((n, 4), np.int32), ms_switch=np.empty((n, nb), np.int32),
+                   scale_factor=np.empty((n, 2, nb), np.int32), bit_alloc=np.empty((n, 2, nb), np.int32),
+                   mantissa=np.empty((n, 2, half), np.int32), reservoir_out=np.empty(n, np.int32))
+        mdct = np.empty((n, 4, half), np.float64) if want_mdct else None
+        self._check(lib.mrc_encode_joint(self._h, n, a, b, _p(left, _f64p), _p(right, _f64p), _p(res_in, _i32p),
+                                         _p(out["overall_scale"], _i32p), _p(out["ms_switch"], _i32p),
+                                         _p(out["scale_factor"], _i32p), _p(out["bit_alloc"], _i32p),
+                                         _p(out["mantissa"], _i32p), _p(out["reservoir_out"], _i32p),
+                                         _p(mdct, _f64p)))
+        if want_mdct:
+            out["mdct"] = mdct
+        return out
+
+    def window(self, blocks, a, b):
+        blocks = _f64(blocks)
+        out = np.empty_like(blocks)
+        self._check(lib.mrc_window(self._h, blocks.shape[0], a, b, _p(blocks, _f64p), _p(out, _f64p)))
+        return out
+
+    def mdct(self, blocks, a, b, apply_window=True):
+        blocks = _f64(blocks)
+        n = blocks.shape[0]
+        lines = np.empty((n, (a + b) // 2), np.float64)
+        scale = np.empty(n, np.int32)
+        self._check(lib.mrc_mdct(self._h, n, a, b, _p(blocks, _f64p), int(bool(apply_window)), _p(lines, _f64p),
+                                 _p(scale, _i32p)))
+        return lines, scale
+
+    def smr(self, blocks, a, b, scaled_lines=None, overall_scale=None, want_thresh=False):
+        blocks = _f64(blocks)
+        n = blocks.shape[0]
+        nb, half = len(self.bands(a, b)), (a + b) // 2
+        smr = np.empty((n, nb), np.float64)
+        thr = np.empty((n, half), np.float64) if want_thresh else None
+        sl = None if scaled_lines is None else _f64(scaled_lines)
+        sc = None if overall_scale is None else _i32(overall_scale)
+        self._check(lib.mrc_smr(self._h, n, a, b, _p(blocks, _f64p), _p(sl, _f64p), _p(sc, _i32p), _p(smr, _f64p),
+                                _p(thr, _f64p)))
+        return (smr, thr) if want_thresh else smr
+
+    def bitalloc(self, budget, max_mant_bits, n_lines, smr):
+        smr = _f64(np.atleast_2d(smr))
+        n, nb = smr.shape
+        budget = _f64(np.broadcast_to(np.asarray(budget, dtype=np.float64), (n,)))
+        nl = _i32(n_lines)
+        bits = np.empty((n, nb), np.int32)
+        left = np.empty(n, np.int32)
+        self._check(lib.mrc_bitalloc(self._h, n, nb, int(max_mant_bits), _p(nl, _i32p), _p(budget, _f64p),
+                                     _p(smr, _f64p), _p(bits, _i32p), _p(left, _i32p)))
+        return bits, left
+
+    def scale_factor(self, v, n_scale_bits, n_mant_bits):
+        v = _f64(np.atleast_1d(v))
+        mb = _i32(np.broadcast_to(np.asarray(n_mant_bits), v.shape))
+        out = np.empty(v.shape, np.int32)
+        self._check(lib.mrc_scale_factor(self._h, v.size, int(n_scale_bits), _p(v, _f64p), _p(mb, _i32p),
+                                         _p(out, _i32p)))
+        return out
+
+    def mantissa(self, x, scale, n_scale_bits, n_mant_bits):
+        x = _f64(np.atleast_1d(x))
+        sc = _i32(np.broadcast_to(np.asarray(scale), x.shape))
+        mb = _i32(np.broadcast_to(np.asarray(n_mant_bits), x.shape))
+        out = np.empty(x.shape, np.int32)
+        self._check(lib.mrc_mantissa(self._h, x.size, int(n_scale_bits), _p(x, _f64p), _p(sc, _i32p), _p(mb, _i32p),
+                                     _p(out, _i32p)))
+        return out
+
+    def ms_switch(self, lines_left, lines_right, n_lines):
+        L, R = _f64(np.atleast_2d(lines_left)), _f64(np.atleast_2d(lines_right))
+        nl = _i32(n_lines)
+        if L.shape != R.shape or L.shape[1] != int(nl.sum()):
+            raise ValueError("line vectors must be [n][sum(n_lines)]")
+        out = np.empty((L.shape[0], len(nl)), np.int32)
+        self._check(lib.mrc_ms_switch(self._h, L.shape[0], len(nl), _p(nl, _i32p), _p(L, _f64p), _p(R, _f64p),
+                                      _p(out, _i32p)))
+        return out
+
+    # ---- device entry points (raw pointers as ints, e.g. torch.Tensor.data_ptr())
+    def dev_encode(self, a, b, n_frames, ch_left, ch_right, frame_stride, offsets, reservoir_in, overall_scale,
+                   ms_switch, bit_alloc, scale_factor, mantissa, reservoir_out, lines_out=None, stream=None):
+        self._check(lib.mrc_dev_encode(self._h, a, b, n_frames, ch_left, ch_right, frame_stride, offsets,
+                                       reservoir_in, overall_scale, ms_switch, bit_alloc, scale_factor, mantissa,
+                                       reservoir_out, lines_out, stream))
+
+    def dev_mdct(self, a, b, n_frames, ch_left, ch_right, frame_stride, offsets, lines, overall_scale, stream=None):
+        self._check(lib.mrc_dev_mdct(self._h, a, b, n_frames, ch_left, ch_right, frame_stride, offsets, lines,
+                                     overall_scale, stream))
+
+    def dev_smr(self, a, b, n_frames, ch_left, ch_right, frame_stride, offsets, lines, overall_scale, smr,
+                thresh=None, stream=None):
+        self._check(lib.mrc_dev_smr(self._h, a, b, n_frames, ch_left, ch_right, frame_stride, offsets, lines,
+                                    overall_scale, smr, thresh, stream))
+
+    def dev_alloc_quant(self, a, b, n_frames, joint, lines, overall_scale, smr, reservoir_in, ms_switch, bit_alloc,
+                        scale_factor, mantissa, reservoir_out, stream=None):
+        self._check(lib.mrc_dev_alloc_quant(self._h, a, b, n_frames, int(joint), lines, overall_scale, smr,
+                                            reservoir_in, ms_switch, bit_alloc, scale_factor, mantissa,
+                                            reservoir_out, stream))
+
+    def set_timing(self, on):
+        self._check(lib.mrc_set_timing(self._h, int(bool(on))))
+
+    def stage_ms(self):
+        ms = np.zeros(3, np.float64)
+        self._check(lib.mrc_get_stage_ms(self._h, _p(ms, _f64p)))
+        return ms

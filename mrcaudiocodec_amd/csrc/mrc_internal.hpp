@@ -1,0 +1,78 @@
+// Internal declarations shared by the host glue (mrc_api.cpp, mrc_tables.cpp) and the gfx950
+// kernels (mrc_kernels.hip).  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "mrc_hip.h"
+
+namespace mrc {
+
+constexpr int kMaxRadices = 8;
+constexpr int kMaxBands = MRC_MAX_BANDS;
+
+// Everything a kernel needs to know about one block shape (a,b).  POD, passed by value; the
+// pointers address one device blob owned by the handle.
+struct DevShape {
+    int a, b, N, halfN, Q, H;        // N = a+b, halfN = N/2 lines, Q = N/4 (MDCT FFT), H = N/2 (psycho FFT)
+    int shift;                       // (b-a)/4: signed circular shift that maps n0=(b+1)/2 to the standard phase
+    int nBands;
+    int peakLast;                    // N/2 - 100 (psychoac.py:160)
+    int nRadQ, nRadH;
+    int radQ[kMaxRadices], radH[kMaxRadices];
+    int nScaleBits, maxMantBits;
+    double twoOverN;                 // 2.0/N (mdct.py:76)
+    double binHz;                    // py2 integer sampleRate/N (psychoac.py:165)
+    double xiDen;                    // (N**2.)*(3./8.) (psychoac.py:151)
+    double budgetMono;               // codecThem.py:299-306 (reservoir added last)
+    double budgetJointPre;           // codecThem.py:381-388 (before `+= bitReservoir`)
+    double blkswA, blkswB;
+    const double* win;               // [N] transition window (window.py:104-121)
+    const double* hann;              // [N] window.py:28-45
+    const double2* pre;              // [Q] exp(-i pi (4n+1)/(4M)), M = N/2
+    const double2* post;             // [Q] exp(-i pi k / M)
+    const double2* wQ;               // [Q] exp(-2 pi i t/Q)
+    const double2* wH;               // [H] exp(-2 pi i t/H)
+    const double2* wN;               // [H] exp(-2 pi i k/N)
+    const double* zb;                // [halfN] Bark(MDCTFreq) (psychoac.py:27-29,142-143)
+    const double* quiet;             // [halfN] Intensity(Thresh(MDCTFreq)) (psychoac.py:155)
+    const int* bandLo;               // [nBands]
+    const int* bandN;                // [nBands]
+    const unsigned char* bandOfLine; // [halfN]
+};
+
+struct HostShape {
+    DevShape dev{};                  // device view (pointers valid on the device)
+    std::vector<int> bandN, bandLo;  // host copies
+    void* blob = nullptr;            // device allocation backing dev.*
+};
+
+// mrc_tables.cpp
+bool build_shape(const mrc_config& cfg, int a, int b, HostShape* out, std::string* err);
+void free_shape(HostShape* s);
+int scale_factor_host(double v, int nScaleBits, int nMantBits);
+
+// mrc_kernels.hip -- launchers (enqueue only)
+hipError_t launch_mdct(const DevShape& S, int64_t nFrames, const double* chL, const double* chR,
+                       int64_t stride, const int64_t* offsets, bool applyWindow, double* lines, int* oscale,
+                       hipStream_t st);
+hipError_t launch_window(const DevShape& S, int64_t nBlocks, const double* in, double* out, hipStream_t st);
+hipError_t launch_unscale(int64_t nBlocks, int halfN, const double* scaled, const int* oscale, double* lines,
+                          hipStream_t st);
+hipError_t launch_smr(const DevShape& S, int64_t nFrames, const double* chL, const double* chR,
+                      int64_t stride, const int64_t* offsets, const double* lines, const int* oscale,
+                      double* smr, double* thresh, hipStream_t st);
+hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, const double* lines,
+                              const int* oscale, const double* smr, const int* resIn, int* msSwitch,
+                              int* bitAlloc, int* scaleFactor, int* mantissa, int* resOut, hipStream_t st);
+hipError_t launch_bitalloc_cases(int64_t nCases, int nBands, int maxMantBits, const int* nLines,
+                                 const double* budget, const double* smr, int* bits, int* left, hipStream_t st);
+hipError_t launch_scale_factor(int64_t n, int nScaleBits, const double* v, const int* nMantBits, int* out,
+                               hipStream_t st);
+hipError_t launch_mantissa(int64_t n, int nScaleBits, const double* x, const int* scale, const int* nMantBits,
+                           int* out, hipStream_t st);
+hipError_t launch_ms_switch(int64_t nBlocks, int nBands, int nTotal, const int* bandLo, const int* bandN,
+                            const double* L, const double* R, int* out, hipStream_t st);
+
+}  // namespace mrc

@@ -1,0 +1,237 @@
+// Host-side constant tables per block shape (a,b): windows, twiddles, band tables, psychoacoustic
+// constants, bit budgets.  Built once at mrc_create / first use of a shape and uploaded as one
+// device blob.  Reference lines are cited per table; everything is a pure function of
+// (a, b, sampleRate, nScaleBits, nMantSizeBits, targetBitsPerSample, blksw bits).
+#include "mrc_internal.hpp"
+
+#include <cmath>
+#include <cstring>
+
+namespace mrc {
+
+namespace {
+
+const long double kPiL = 3.14159265358979323846264338327950288L;
+
+// Modified Bessel function I0 by its power series (all terms positive, no cancellation), long double.
+long double bessel_i0(long double x) {
+    long double q = x * x / 4.0L, term = 1.0L, sum = 1.0L;
+    for (int k = 1; k < 500; ++k) {
+        term *= q / ((long double)k * (long double)k);
+        sum += term;
+        if (term < 1e-24L * sum) break;
+    }
+    return sum;
+}
+
+// window.py:49-101 -- Kaiser-Bessel-derived window, alpha = 4, length N: kernel
+// w[j] = I0(pi a sqrt(1-((j-M/2)/(M/2))^2))/I0(pi a), j = 0..M = N/2; rising half
+// sqrt(sum_{j<=n} w^2 / sum_{0..M} w^2), falling half sqrt(sum_{j>=i+1} w^2 / total).
+std::vector<double> kbd_table(int N, long double alpha = 4.0L) {
+    const int M = N / 2;
+    std::vector<long double> w2(M + 1);
+    const long double den = bessel_i0(kPiL * alpha);
+    long double total = 0.0L;
+    for (int j = 0; j <= M; ++j) {
+        long double r = ((long double)j - M / 2.0L) / (M / 2.0L);
+        long double rad = 1.0L - r * r;
+        if (rad < 0.0L) rad = 0.0L;
+        long double k = bessel_i0(kPiL * alpha * sqrtl(rad)) / den;
+        w2[j] = k * k;
+        total += w2[j];
+    }
+    std::vector<double> win(N);
+    long double run = 0.0L;
+    for (int n = 0; n < M; ++n) {
+        run += w2[n];
+        win[n] = (double)sqrtl(run / total);
+    }
+    run = 0.0L;
+    for (int i = M - 1; i >= 0; --i) {
+        run += w2[i + 1];
+        win[M + i] = (double)sqrtl(run / total);
+    }
+    return win;
+}
+
+double thresh_quiet_db(double f) {                    // psychoac.py:20-25
+    double k = f / 1000.;
+    double d = k - 3.3;
+    return (3.64 * std::pow(k, -0.8)) - (6.5 * std::exp(-0.6 * (d * d))) + (0.001 * std::pow(k, 4.0));
+}
+
+double bark(double f) {                               // psychoac.py:27-29
+    double q = f / 7500.;
+    return 13 * std::atan(0.76 * f / 1000.) + 3.5 * std::atan(q * q);
+}
+
+bool factor(int n, int* rad, int* nrad) {
+    int c = 0;
+    while (n % 4 == 0 && c < kMaxRadices) { rad[c++] = 4; n /= 4; }
+    while (n % 2 == 0 && c < kMaxRadices) { rad[c++] = 2; n /= 2; }
+    while (n % 3 == 0 && c < kMaxRadices) { rad[c++] = 3; n /= 3; }
+    *nrad = c;
+    return n == 1;
+}
+
+// psychoac.py:82-84 and pacfileThem.py:643
+const int kLongLimits[25] = {100, 200, 300, 400, 510, 630, 770, 920, 1080, 1270, 1480, 1720, 2000, 2320,
+                             2700, 3150, 3700, 4400, 5300, 6400, 7700, 9500, 12000, 15500, 24000};
+const int kShortLimits[9] = {300, 630, 1080, 1720, 2700, 4400, 7700, 15500, 24000};
+
+struct BlobWriter {
+    std::vector<unsigned char> bytes;
+    template <class T> size_t put(const std::vector<T>& v) {
+        size_t off = (bytes.size() + 15) & ~size_t(15);
+        bytes.resize(off + v.size() * sizeof(T));
+        std::memcpy(bytes.data() + off, v.data(), v.size() * sizeof(T));
+        return off;
+    }
+};
+
+std::vector<double2> unit_circle(int n, long double scale /* angle = -scale * t */) {
+    std::vector<double2> w(n);
+    for (int t = 0; t < n; ++t) {
+        long double ang = -scale * (long double)t;
+        w[t] = make_double2((double)cosl(ang), (double)sinl(ang));
+    }
+    return w;
+}
+
+}  // namespace
+
+// quantize.py:114-146 on the host (used for validation of configs only; the device has its own copy).
+int scale_factor_host(double v, int nScaleBits, int nMantBits) {
+    int nBits = (1 << nScaleBits) - 1 + nMantBits;
+    double mag = std::fabs(v);
+    long long code;
+    if (mag >= 1.0) code = (1LL << (nBits - 1)) - 1;
+    else code = (long long)((((double)((1LL << nBits) - 1)) * mag + 1.0) / 2.0);
+    int top = 0;
+    if (code > 0) top = 63 - __builtin_clzll((unsigned long long)code);
+    int lz = (nBits - 2) - top;
+    int cap = (1 << nScaleBits) - 1;
+    return lz < cap ? lz : cap;
+}
+
+bool build_shape(const mrc_config& cfg, int a, int b, HostShape* out, std::string* err) {
+    const int N = a + b;
+    if (a <= 0 || b <= 0 || N % 4 != 0 || (b - a) % 4 != 0) {
+        *err = "block shape (a,b) must be positive with a+b and b-a divisible by 4";
+        return false;
+    }
+    DevShape& S = out->dev;
+    S = DevShape{};
+    S.a = a; S.b = b; S.N = N; S.halfN = N / 2; S.Q = N / 4; S.H = N / 2;
+    S.shift = (b - a) / 4;
+    S.peakLast = N / 2 - 100;
+    if (S.peakLast < 3) { *err = "block too short for the peak search (N/2-100 < 3)"; return false; }
+    if (!factor(S.Q, S.radQ, &S.nRadQ) || !factor(S.H, S.radH, &S.nRadH)) {
+        *err = "block length must factor into 2s and 3s";
+        return false;
+    }
+    S.nScaleBits = cfg.n_scale_bits;
+    S.maxMantBits = (1 << cfg.n_mant_size_bits) > 16 ? 16 : (1 << cfg.n_mant_size_bits);   // codecThem.py:292-293
+    S.twoOverN = 2.0 / N;
+    S.binHz = (double)(cfg.sample_rate / N);                  // py2 integer division (psychoac.py:165)
+    S.xiDen = ((double)N * (double)N) * (3. / 8.);
+
+    // band table: psychoac.py:86-105 with the limits chosen at pacfileThem.py:637-645
+    const bool isLong = (N == 2 * cfg.n_mdct_lines);
+    const int* lim = isLong ? kLongLimits : kShortLimits;
+    const int nb = isLong ? 25 : 9;
+    std::vector<int> count(nb, 0);
+    {
+        int j = 0;
+        for (int i = 0; i < nb - 1; ++i) {
+            while (j < S.halfN && (j + 0.5) * (((double)cfg.sample_rate / S.halfN) / 2.) < lim[i]) { ++count[i]; ++j; }
+        }
+        count[nb - 1] = S.halfN - j;
+        if (count[nb - 1] < 0) { *err = "band table overflow"; return false; }
+    }
+    S.nBands = nb;
+    out->bandN = count;
+    out->bandLo.assign(nb, 0);
+    for (int i = 1; i < nb; ++i) out->bandLo[i] = out->bandLo[i - 1] + count[i - 1];
+    std::vector<unsigned char> bandOfLine(S.halfN);
+    for (int i = 0; i < nb; ++i)
+        for (int k = 0; k < count[i]; ++k) bandOfLine[out->bandLo[i] + k] = (unsigned char)i;
+
+    // bit budgets: codecThem.py:299-306 (mono) and 381-388 (joint, before the reservoir is added)
+    {
+        double halfN = (a + b) / 2.;
+        double m = cfg.target_bits_per_sample * halfN;
+        m -= cfg.n_scale_bits * (nb + 1);
+        m -= cfg.n_mant_size_bits * nb;
+        m -= cfg.blksw_bits_a;
+        m -= cfg.blksw_bits_b;
+        S.budgetMono = m;
+        double j = cfg.target_bits_per_sample * halfN;
+        j -= cfg.n_scale_bits * nb;
+        j -= cfg.n_mant_size_bits * nb;
+        j += j;
+        j -= nb;
+        j -= cfg.n_scale_bits * 4;
+        S.budgetJointPre = j;
+        S.blkswA = cfg.blksw_bits_a;
+        S.blkswB = cfg.blksw_bits_b;
+    }
+
+    // windows
+    std::vector<double> win(N), hann(N);
+    {
+        std::vector<double> ka = kbd_table(2 * a), kb = (a == b) ? ka : kbd_table(2 * b);
+        for (int n = 0; n < a; ++n) win[n] = ka[n];
+        for (int i = 0; i < b; ++i) win[a + i] = kb[b + i];
+        for (int n = 0; n < N; ++n)                      // window.py:38-42
+            hann[n] = 0.5 + (-0.5 * std::cos(((2.0 * M_PI) / N) * (n + 0.5)));
+    }
+    // twiddles
+    const int M = S.halfN;
+    std::vector<double2> pre(S.Q), post(S.Q);
+    for (int n = 0; n < S.Q; ++n) {
+        long double ang = -kPiL * (4.0L * n + 1.0L) / (4.0L * M);
+        pre[n] = make_double2((double)cosl(ang), (double)sinl(ang));
+        long double ang2 = -kPiL * (long double)n / (long double)M;
+        post[n] = make_double2((double)cosl(ang2), (double)sinl(ang2));
+    }
+    std::vector<double2> wQ = unit_circle(S.Q, 2.0L * kPiL / S.Q);
+    std::vector<double2> wH = unit_circle(S.H, 2.0L * kPiL / S.H);
+    std::vector<double2> wN = unit_circle(S.H, 2.0L * kPiL / N);
+    // psychoacoustic constants on the MDCT line grid (psychoac.py:142-143,155)
+    std::vector<double> zb(S.halfN), quiet(S.halfN);
+    for (int k = 0; k < S.halfN; ++k) {
+        double f = (k + 0.5) * (((double)cfg.sample_rate / S.halfN) / 2.);
+        zb[k] = bark(f);
+        quiet[k] = std::pow(10.0, (thresh_quiet_db(f) - 96) / 10);
+    }
+
+    BlobWriter bw;
+    size_t oWin = bw.put(win), oHann = bw.put(hann), oPre = bw.put(pre), oPost = bw.put(post);
+    size_t oWQ = bw.put(wQ), oWH = bw.put(wH), oWN = bw.put(wN), oZb = bw.put(zb), oQuiet = bw.put(quiet);
+    size_t oLo = bw.put(out->bandLo), oCnt = bw.put(out->bandN), oBol = bw.put(bandOfLine);
+    void* blob = nullptr;
+    if (hipMalloc(&blob, bw.bytes.size()) != hipSuccess) { *err = "hipMalloc(shape tables) failed"; return false; }
+    if (hipMemcpy(blob, bw.bytes.data(), bw.bytes.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(blob);
+        *err = "hipMemcpy(shape tables) failed";
+        return false;
+    }
+    unsigned char* base = (unsigned char*)blob;
+    S.win = (const double*)(base + oWin);       S.hann = (const double*)(base + oHann);
+    S.pre = (const double2*)(base + oPre);      S.post = (const double2*)(base + oPost);
+    S.wQ = (const double2*)(base + oWQ);        S.wH = (const double2*)(base + oWH);
+    S.wN = (const double2*)(base + oWN);
+    S.zb = (const double*)(base + oZb);         S.quiet = (const double*)(base + oQuiet);
+    S.bandLo = (const int*)(base + oLo);        S.bandN = (const int*)(base + oCnt);
+    S.bandOfLine = (const unsigned char*)(base + oBol);
+    out->blob = blob;
+    return true;
+}
+
+void free_shape(HostShape* s) {
+    if (s->blob) (void)hipFree(s->blob);
+    s->blob = nullptr;
+}
+
+}  // namespace mrc

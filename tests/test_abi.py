@@ -1,0 +1,91 @@
+"""
+CPU-side checks of the boundary: the shared library loads, exports every function include/mrc_hip.h
+declares, refuses to run without a GPU (no CPU fallback), and the host-side logic (Huffman stage,
+synthetic inputs, table data) agrees with the oracle.  No kernel is launched here.
+"""
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+
+from oracle import codec as ocodec, huffman_tables as otables
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "mrc_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mrc_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_header_symbol():
+    from mrcaudiocodec_amd import _lib
+    import ctypes
+    names = _header_functions()
+    assert len(names) >= 20
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), "libmrc_hip.so does not export %s" % n
+        assert n in _lib.EXPORTS, "ctypes binding does not declare %s" % n
+    assert _lib.lib.mrc_version() == 100
+
+
+def test_no_cpu_fallback_without_gpu():
+    from mrcaudiocodec_amd import Handle, MrcError, _lib
+    if _lib.lib.mrc_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(MrcError):
+        Handle()
+    import mrcaudiocodec_amd.codecThem as codec
+    cp = ocodec.default_params()
+    with pytest.raises(MrcError):
+        codec.EncodeSingleChannel(np.zeros(2048), cp)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "mrcaudiocodec_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "oracle/" not in src, f
+
+
+def test_huffman_tables_match_oracle():
+    from mrcaudiocodec_amd import huffman_tables as pt
+    assert pt.TABLE_NAMES == otables.TABLE_ORDER and pt.RAW_TABLE_ID == otables.RAW_TABLE_ID
+    for name in pt.TABLE_NAMES:
+        table, esc = otables.TABLES[name]
+        assert pt.ESCAPE[name] == esc
+        assert {v: c for v, (c, _) in table.items()} == pt.CODES[name]
+
+
+def test_huffman_gain_host_logic_matches_oracle():
+    import mrcaudiocodec_amd.codecThem as codec
+    rng = np.random.default_rng(7)
+    cp = ocodec.default_params()
+    for trial in range(40):
+        ba = rng.choice([0, 0, 2, 3, 4, 5, 7], size=25)
+        n = int(np.sum(cp.sfBands.nLines[ba > 0]))
+        scale = [1, 2, 4, 20][trial % 4]
+        m = np.abs(np.rint(rng.laplace(0, scale, n))).astype(np.int32)
+        m = np.minimum(m, 2 ** 15)
+        got = codec.calculateHuffmanGain(m, ba, cp)
+        want = ocodec.calculateHuffmanGain(m, ba, cp)
+        assert got[0] == want[0] and got[2] == want[2]
+        assert list(got[1]) == list(want[1])
+
+
+def test_synth_shapes():
+    from mrcaudiocodec_amd import synth
+    assert synth.c2_noise(3).shape == (4 * 1024,) and not synth.c2_noise(3)[:1024].any()
+    assert synth.c3_stereo(3).shape == (2, 4 * 1024)
+    x, shapes = synth.c4_transients(10)
+    assert shapes[4] == (4096, 1024, 128) and shapes[5][1:] == (128, 128) and shapes[12][1:] == (128, 1024)
+    assert shapes[-1][0] + shapes[-1][1] + shapes[-1][2] == len(x)
+    assert np.abs(x).max() <= 1.0
+    assert synth.pcm_to_float([1])[0] == 3.0518043793392844e-05

@@ -1,0 +1,266 @@
+"""
+GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the C ABI of libmrc_hip.so
+(ctypes, mrcaudiocodec_amd._lib) and is compared with
+  * the golden vectors recorded from the reference's own modules (tests/golden/*.npz) -- bit-exact,
+  * the oracle (oracle.fast / oracle.codec) on the same seeded inputs -- bit-exact for every integer
+    output (overall scale, M/S switch, bit allocation, scale factors, mantissas, reservoir), and
+    |dX| <= 1e-12 * max|X| for MDCT lines, <= 1e-9 dB for thresholds / SMRs (float64 transcendental
+    implementations differ in the last ulps between libm and the device; see DESIGN.md "Parity policy").
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import codec as ocodec, fast
+
+pytestmark = pytest.mark.gpu
+
+MDCT_RTOL = 1e-12
+DB_ATOL = 1e-9
+SHAPES = [(1024, 1024), (128, 128), (1024, 128), (128, 1024)]
+
+
+@pytest.fixture(scope="module")
+def h():
+    from mrcaudiocodec_amd import Handle
+    hd = Handle(device_id=0)
+    yield hd
+    hd.close()
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _int_keys(joint):
+    return ("overall_scale", "bit_alloc", "scale_factor", "mantissa", "reservoir_out") + (("ms_switch",) if joint else ())
+
+
+def _assert_int_parity(got, ref, joint=False):
+    for k in _int_keys(joint):
+        bad = np.argwhere(np.asarray(got[k]) != np.asarray(ref[k]))
+        assert bad.size == 0, "%s: %d mismatching entries, first at %s" % (k, len(bad), bad[0])
+
+
+# ------------------------------------------------------------------ golden vectors of the reference's own modules
+def test_scale_factor_golden(h, golden_dir):
+    g = _load(golden_dir, "quantize.npz")
+    for (s, m), want in zip(g["sf_cases"], g["sf_out"]):
+        assert np.array_equal(h.scale_factor(g["vals"], int(s), int(m)), want)
+
+
+def test_mantissa_golden(h, golden_dir):
+    g = _load(golden_dir, "quantize.npz")
+    for (sc, sb, mb), want in zip(g["mant_cases"], g["vmant_out"]):
+        assert np.array_equal(h.mantissa(g["vals"], int(sc), int(sb), int(mb)), want.astype(np.int64))
+
+
+def test_bitalloc_golden(h, golden_dir):
+    g = _load(golden_dir, "bitalloc.npz")
+    for i in range(int(g["n"])):
+        bits, left = h.bitalloc(float(g["budget_%d" % i]), int(g["maxb_%d" % i]), g["nlines_%d" % i], g["smr_%d" % i])
+        assert np.array_equal(bits[0], g["bits_%d" % i].astype(np.int64)), i
+        assert int(left[0]) == int(g["left_%d" % i]), i
+
+
+def test_ms_switch_golden(h, golden_dir):
+    g = _load(golden_dir, "ms_stereo.npz")
+    for k in range(int(g["n"])):
+        got = h.ms_switch(g["L_%d" % k], g["R_%d" % k], g["nlines_%d" % k])[0]
+        assert np.array_equal(got, g["switch_%d" % k]), k
+
+
+# ------------------------------------------------------------------ stages vs oracle
+def _noise_blocks(a, b, n, seed=99, sigma=0.1):
+    from mrcaudiocodec_amd import synth
+    x = synth.pcm_to_float(np.clip(np.rint(np.random.default_rng(seed).normal(0, sigma * 32767, n * b + a)), -32767, 32767))
+    return np.stack([x[i * b:i * b + a + b] for i in range(n)])
+
+
+@pytest.mark.parametrize("ab", SHAPES)
+def test_window_and_mdct(h, ab):
+    a, b = ab
+    blocks = _noise_blocks(a, b, 64)
+    tbl = fast.transition_table(a, b)
+    w = h.window(blocks, a, b)
+    assert np.abs(w - blocks * tbl).max() <= 4e-16          # table built in long double vs NumPy's dense sums
+    X, scale = h.mdct(blocks, a, b)
+    ref = fast.mdct_batch(blocks, a, b)
+    assert np.abs(X - ref).max() <= MDCT_RTOL * np.abs(ref).max()
+    assert np.array_equal(scale, fast.overall_scale_batch(ref, 4)[0])
+    # un-windowed entry (mdct.MDCT signature) against the O(N^2) definition on one block
+    from oracle import mdct as omdct
+    X0 = h.mdct(blocks[:1], a, b, apply_window=False)[0][0]
+    d = omdct.MDCTslow(blocks[0], a, b)
+    assert np.abs(X0 - d).max() <= MDCT_RTOL * np.abs(d).max() * 10
+
+
+@pytest.mark.parametrize("ab", SHAPES)
+def test_threshold_and_smr(h, ab):
+    a, b = ab
+    blocks = _noise_blocks(a, b, 48, seed=5)
+    smr, thr = h.smr(blocks, a, b, want_thresh=True)
+    sfb = fast.bands_for(a, b)
+    X = fast.mdct_batch(blocks, a, b)
+    s, Xs = fast.overall_scale_batch(X, 4)
+    assert np.abs(thr - fast.masked_threshold_batch(blocks, (a + b) // 2, 48000)).max() <= DB_ATOL
+    assert np.abs(smr - fast.smr_batch(blocks, Xs, s, 48000, sfb)).max() <= DB_ATOL
+    # CalcSMRs-style entry: caller supplies the scaled lines
+    smr2 = h.smr(blocks, a, b, scaled_lines=Xs, overall_scale=s)
+    assert np.abs(smr2 - smr).max() <= DB_ATOL
+
+
+# ------------------------------------------------------------------ whole path, bit-exact integers
+def test_encode_mono_noise_long(h):
+    from mrcaudiocodec_amd import synth
+    n = 768
+    blocks = np.array(fast.blocks_from_stream(synth.c2_noise(n), 1024))
+    res_in = np.random.default_rng(3).integers(-200, 600, n)
+    got = h.encode_mono(blocks, 1024, 1024, res_in, want_mdct=True)
+    ref = fast.encode_mono_batch(blocks, 1024, 1024, res_in)
+    _assert_int_parity(got, ref)
+    assert np.abs(got["mdct"] - ref["mdct"]).max() <= MDCT_RTOL * np.abs(ref["mdct"]).max()
+
+
+def test_encode_joint_ms_long(h):
+    from mrcaudiocodec_amd import synth
+    n = 384
+    s = synth.c3_stereo(n)
+    bl, br = np.array(fast.blocks_from_stream(s[0], 1024)), np.array(fast.blocks_from_stream(s[1], 1024))
+    got = h.encode_joint(bl, br, 1024, 1024, want_mdct=True)
+    ref = fast.encode_joint_batch(bl, br, 1024, 1024)
+    _assert_int_parity(got, ref, joint=True)
+    assert 0 < ref["ms_switch"].mean() < 1                     # both branches of the switch occur
+    assert np.abs(got["mdct"] - ref["mdct"]).max() <= MDCT_RTOL * np.abs(ref["mdct"]).max()
+
+
+@pytest.mark.parametrize("ab", SHAPES[1:])
+def test_encode_short_and_transition(h, ab):
+    a, b = ab
+    blocks = _noise_blocks(a, b, 256, seed=42, sigma=0.3)
+    res_in = np.random.default_rng(4).integers(-100, 100, 256)
+    _assert_int_parity(h.encode_mono(blocks, a, b, res_in), fast.encode_mono_batch(blocks, a, b, res_in))
+    right = _noise_blocks(a, b, 256, seed=43, sigma=0.3)
+    mixed = np.where((np.arange(256) % 2 == 0)[:, None], 0.9 * blocks + 0.1 * right, right)
+    _assert_int_parity(h.encode_joint(blocks, mixed, a, b), fast.encode_joint_batch(blocks, mixed, a, b), joint=True)
+
+
+def test_block_switching_stream(h):
+    from mrcaudiocodec_amd import synth
+    x, shapes = synth.c4_transients(25)
+    for (a, b) in SHAPES:
+        offs = [o for (o, aa, bb) in shapes if (aa, bb) == (a, b)]
+        blocks = np.stack([x[o:o + a + b] for o in offs])
+        _assert_int_parity(h.encode_mono(blocks, a, b), fast.encode_mono_batch(blocks, a, b))
+
+
+def test_edge_blocks(h):
+    # digital silence, full scale square wave (clipping branch |x| >= 1 of the quantiser), a single impulse, 1 kHz sine
+    from mrcaudiocodec_amd import synth
+    sil = np.zeros(2048)
+    sq = np.where((np.arange(2048) // 24) % 2 == 0, 1.0, -1.0) * (32767 * 2.0 / 65535)
+    imp = np.zeros(2048); imp[1500] = 0.9
+    sine = synth.c1_sine(2)[1024:3072]
+    blocks = np.stack([sil, sq, imp, sine])
+    got = h.encode_mono(blocks, 1024, 1024, want_mdct=True)
+    ref = fast.encode_mono_batch(blocks, 1024, 1024)
+    _assert_int_parity(got, ref)
+    assert got["overall_scale"][0] == 15 and not got["mantissa"][0].any()
+    gj = h.encode_joint(blocks, blocks[::-1].copy(), 1024, 1024)
+    _assert_int_parity(gj, fast.encode_joint_batch(blocks, blocks[::-1].copy(), 1024, 1024), joint=True)
+    # L == R exactly: side channel is digital silence, ties between the two streams stay ties
+    gj = h.encode_joint(blocks, blocks.copy(), 1024, 1024)
+    _assert_int_parity(gj, fast.encode_joint_batch(blocks, blocks.copy(), 1024, 1024), joint=True)
+    # empty batch
+    e = h.encode_mono(np.zeros((0, 2048)), 1024, 1024)
+    assert e["mantissa"].shape == (0, 1024)
+
+
+def test_bad_arguments(h):
+    from mrcaudiocodec_amd import MrcError
+    with pytest.raises(MrcError):
+        h.mdct(np.zeros((1, 30)), 15, 15)                       # N not divisible by 4
+    with pytest.raises(ValueError):
+        h.encode_mono(np.zeros((1, 100)), 1024, 1024)
+
+
+# ------------------------------------------------------------------ the drop-in module, chained like the reference's caller
+def _chain_params(nch):
+    cp = ocodec.default_params(nChannels=nch)
+    return cp
+
+
+def test_dropin_encode_chain_mono(h):
+    import mrcaudiocodec_amd.codecThem as codec
+    from mrcaudiocodec_amd import synth
+    x = synth.c2_noise(24)
+    cp_g, cp_o = _chain_params(1), _chain_params(1)
+    for i in range(24):
+        blk = [x[i * 1024:i * 1024 + 2048]]
+        g = codec.Encode(blk, cp_g)
+        o = ocodec.Encode([blk[0].copy()], cp_o)
+        assert cp_g.bitReservoir == cp_o.bitReservoir
+        assert np.array_equal(g[0][0], o[0][0]) and np.array_equal(g[1][0], o[1][0])
+        assert list(g[2][0]) == list(o[2][0]) and g[3] == o[3] and g[4] == o[4]
+        assert g[0][0].dtype == np.int32
+
+
+def test_dropin_joint_chain_and_l1_names(h):
+    import mrcaudiocodec_amd.codecThem as codec
+    from mrcaudiocodec_amd import synth
+    s = synth.c3_stereo(12)
+    cp_g, cp_o = _chain_params(2), _chain_params(2)
+    for i in range(12):
+        blk = [s[0, i * 1024:i * 1024 + 2048], s[1, i * 1024:i * 1024 + 2048]]
+        g = codec.JointEncode(blk, cp_g)
+        o = ocodec.JointEncode([b.copy() for b in blk], cp_o)
+        assert cp_g.bitReservoir == cp_o.bitReservoir
+        for c in range(2):
+            assert np.array_equal(g[0][c], o[0][c]) and np.array_equal(g[1][c], o[1][c])
+            assert list(g[2][c]) == list(o[2][c])
+        assert list(g[3]) == list(o[3]) and list(g[4]) == list(o[4]) and g[5] == o[5]
+    # L1 helpers keep the reference's signatures
+    from oracle import quantize as oq, bitalloc as ob, ms_stereo as om, psychoac as op, mdct as omd, window as ow
+    x = s[0, 1024:3072]
+    assert np.abs(codec.TransitionWindow(x, 1024, 1024) - ow.TransitionWindow(x, 1024, 1024)).max() < 4e-16
+    xw = ow.TransitionWindow(x, 1024, 1024)
+    X = omd.MDCT(xw, 1024, 1024)
+    assert np.abs(codec.MDCT(xw, 1024, 1024) - X).max() <= MDCT_RTOL * np.abs(X).max()
+    assert codec.ScaleFactor(0.013, 4, 3) == oq.ScaleFactor(0.013, 4, 3)
+    v = np.array([0.01, -0.3, 0.0, 0.7])
+    assert np.array_equal(codec.vMantissa(v, 2, 4, 5), oq.vMantissa(v, 2, 4, 5))
+    smr = np.random.default_rng(1).normal(5, 10, 25)
+    gb, gl = codec.BitAlloc(2722.64, 16, 25, cp_o.sfBands.nLines, smr.copy())
+    wb, wl = ob.BitAlloc(2722.64, 16, 25, cp_o.sfBands.nLines, smr.copy())
+    assert np.array_equal(gb, wb) and gl == wl
+    sc = oq.ScaleFactor(np.max(np.abs(X)), 4)
+    Xs = X * (1 << sc)
+    assert np.abs(codec.CalcSMRs(x, Xs, sc, 48000, cp_o.sfBands) - op.CalcSMRs(x, Xs.copy(), sc, 48000, cp_o.sfBands)).max() <= DB_ATOL
+    assert codec.MSSwitchSFBands(X, 0.5 * X, cp_o.sfBands) == om.MSSwitchSFBands(X, 0.5 * X, cp_o.sfBands)
+
+
+# ------------------------------------------------------------------ device API: overlapped stream layout (each hop read once)
+def test_device_stream_layout_matches_blocks(h):
+    torch = pytest.importorskip("torch")
+    from mrcaudiocodec_amd import synth
+    from mrcaudiocodec_amd.batch import StreamEncoder
+    n = 300
+    s = synth.c3_stereo(n)
+    enc = StreamEncoder(handle=h)
+    dev = torch.from_numpy(s).to("cuda:0")
+    out = enc.encode_long(dev[0], None, n)
+    ref = h.encode_mono(np.array(fast.blocks_from_stream(s[0], 1024)), 1024, 1024)
+    for k in _int_keys(False):
+        assert np.array_equal(out[k].cpu().numpy().reshape(ref[k].shape), ref[k]), k
+    outj = enc.encode_long(dev[0], dev[1], n)
+    refj = h.encode_joint(np.array(fast.blocks_from_stream(s[0], 1024)), np.array(fast.blocks_from_stream(s[1], 1024)),
+                          1024, 1024)
+    for k in _int_keys(True):
+        assert np.array_equal(outj[k].cpu().numpy().reshape(refj[k].shape), refj[k]), k
+    # size-independent property at a larger batch: frame f of a stream == frame 0 of the stream shifted by f hops
+    big = torch.from_numpy(synth.c2_noise(4096)).to("cuda:0")
+    full = enc.encode_long(big, None, 4096)
+    part = enc.encode_long(big[1024 * 1000:], None, 96)
+    for k in _int_keys(False):
+        assert torch.equal(full[k][1000:1096], part[k]), k
