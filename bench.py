@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""
+bench.py -- encode throughput of the MI355X hot path (BASELINE.json metric: encode Msamples/s,
+48 kHz, 2048-point MDCT blocks).
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W               (N > 1, one rank per GPU)
+
+A step = one pass of the whole hot path (window+MDCT -> masked threshold/SMR -> bit allocation ->
+scale factors + mantissas) over one batch of synthetic PCM frames that is already resident in HBM.
+Workload at every N: BASELINE.json configs[1] -- mono 48 kHz Gaussian white noise (sigma 0.1 FS,
+16-bit PCM grid), all-long blocks (a=b=1024), independent-frames mode (reservoir_in = 0), F frames per
+GPU per step in the hop-overlapped stream layout.  Frames shard across ranks as disjoint streams with
+no collective ("weak" scaling: per-GPU work fixed).  Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      dominant kernel (largest share of device time): algorithmic bytes per launch / its
+                average duration measured with hipEvents on the launch stream, against 8 TB/s HBM.
+  kernels       the same for every kernel of the path (the MDCT kernel is the one north_star prices
+                against the HBM roofline; the SMR kernel is fp64-VALU bound).
+  cpu_baseline  the oracle's faithful NumPy port of the reference path, 1 core, bounded sample (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HOP = 1024
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
+# algorithmic bytes per long (frame, channel) -- DESIGN.md "Algorithmic bytes"
+BYTES_MDCT = 8192 + 8192                          # one new hop in (f64) + 1024 lines out (f64)
+BYTES_SMR = 8192 + 8192 + 4 + 25 * 8              # hop in + lines in + overall scale in + 25 SMRs out
+BYTES_ALLOC = 8192 + 4 + 25 * 8 + 4 + 4096 + 100 + 100 + 4   # lines, scale, SMRs, reservoir in; mantissas, sf, ba, reservoir out
+BYTES_PATH = 12496                                # hop in + all integer outputs
+
+
+def make_noise_stream(torch, device, n_frames, seed):
+    """C2 content generated on the device: 16-bit Gaussian PCM mapped to signed fractions
+    (pcmfile.py:91-100), one leading hop of zeros (priorBlock at file start)."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    pcm = torch.randn((n_frames * HOP,), generator=g, device=device, dtype=torch.float64) * (0.1 * 32767)
+    pcm = torch.clamp(torch.round(pcm), -32767, 32767)
+    x = torch.sign(pcm) * 2.0 * torch.abs(pcm) / 65535
+    return torch.cat([torch.zeros(HOP, device=device, dtype=torch.float64), x]).contiguous()
+
+
+def cpu_baseline(n_frames):
+    """The faithful one-block-at-a-time NumPy port (oracle.codec), single core, on the same kind of stream."""
+    import numpy as np
+    from mrcaudiocodec_amd import synth
+    from oracle import codec as ocodec, fast
+    x = synth.c2_noise(n_frames + 1)
+    cp = ocodec.default_params()
+    ocodec.EncodeSingleChannel(x[0:2048].copy(), cp)              # warm-up frame
+    t0 = time.perf_counter()
+    for i in range(1, n_frames + 1):
+        cp.bitReservoir = 0
+        ocodec.EncodeSingleChannel(x[i * HOP:i * HOP + 2048].copy(), cp)
+    dt = time.perf_counter() - t0
+    blocks = np.array(fast.blocks_from_stream(x, HOP))
+    t1 = time.perf_counter()
+    fast.encode_mono_batch(blocks, 1024, 1024)
+    dtv = time.perf_counter() - t1
+    return {"value": n_frames * HOP / dt / 1e6, "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": "%d long mono frames of the same synthetic noise, oracle.codec.EncodeSingleChannel "
+                      "(faithful NumPy port of codecThem.py:281-354), %.1f s" % (n_frames, dt),
+            "vectorised_port_value": blocks.shape[0] * HOP / dtv / 1e6}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=1 << 17, help="frames per GPU per step")
+    ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from mrcaudiocodec_amd.batch import StreamEncoder
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    enc = StreamEncoder(device_id=local)
+    F = args.frames
+    pcm = make_noise_stream(torch, device, F, seed=1234 + rank)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        enc.encode_long(pcm, None, F)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        enc.encode_long(pcm, None, F)
+    torch.cuda.synchronize(device)
+    elapsed = time.perf_counter() - t0
+    barrier()
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # per-kernel device time, hipEvents on the launch stream (outside the timed region)
+    enc.h.set_timing(True)
+    import numpy as np
+    reps = max(3, min(args.steps, 10))
+    acc = np.zeros(3)
+    for _ in range(reps):
+        enc.encode_long(pcm, None, F)
+        acc += enc.h.stage_ms()
+    enc.h.set_timing(False)
+    stage_ms = acc / reps
+
+    if rank == 0:
+        total_samples = float(F) * HOP * world * args.steps
+        names = ["mdct_kernel", "smr_kernel", "alloc_quant_kernel"]
+        per_unit = [BYTES_MDCT, BYTES_SMR, BYTES_ALLOC]
+        kernels = []
+        for nm, ms, bpu in zip(names, stage_ms, per_unit):
+            gbs = bpu * F / (ms * 1e-3) / 1e9
+            kernels.append({"name": nm, "ms": round(float(ms), 4), "algorithmic_bytes": bpu * F,
+                            "achieved_GBs": round(gbs, 2), "frac_hbm": round(gbs / HBM_PEAK_GBS, 5)})
+        dom = int(np.argmax(stage_ms))
+        line = {
+            "metric": "encode Msamples/sec (48 kHz, 2048-pt MDCT)",
+            "value": round(total_samples / elapsed / 1e6, 3),
+            "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[1]: mono 48 kHz white noise (sigma 0.1 FS, 16-bit grid), 2048-pt long blocks, "
+                                   "whole encode path, independent-frames mode",
+                       "frames_per_gpu_per_step": F, "hop": HOP, "layout": "hop-overlapped f64 stream in HBM",
+                       "parallelism": "frame-sharded x%d, no collective" % world},
+            "roofline": {"kernel": names[dom], "bound": "hbm", "achieved": kernels[dom]["achieved_GBs"],
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[dom]["frac_hbm"], "traffic": None,
+                         "note": "dominant kernel by device time; the SMR kernel is limited by fp64 VALU "
+                                 "(10^x per masker x line), not by HBM -- see DESIGN.md"},
+            "kernels": kernels,
+            "whole_path": {"algorithmic_bytes_per_frame": BYTES_PATH,
+                           "achieved_GBs": round(BYTES_PATH * F * world * args.steps / elapsed / 1e9, 2)},
+        }
+        if world == 1 and args.cpu_frames > 0:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_frames)
+            line["speedup_vs_cpu_port"] = round(line["value"] / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,11 +27,29 @@ class MrcError(RuntimeError):
     pass
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so (SONAME
+    libamdhip64.so.7); if libmrc_hip.so pulled in /opt/rocm's copy first, a later `import torch` would
+    load a second runtime that cannot see the GPU, and device pointers / streams could not be shared.
+    So when torch is installed, its copy is loaded first (by path, nothing of torch is imported) and
+    satisfies libmrc_hip.so's NEEDED entry; otherwise the system runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def _load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "mrcaudiocodec_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C mrcaudiocodec_amd/csrc` (hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+    _preload_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     H = C.c_void_p
     sig = {

@@ -156,11 +156,16 @@ def test_block_switching_stream(h):
 
 
 def test_edge_blocks(h):
-    # digital silence, full scale square wave (clipping branch |x| >= 1 of the quantiser), a single impulse, 1 kHz sine
+    # digital silence, full-scale square wave, a 16-bit two-tone burst, 1 kHz sine.
+    # (A lone impulse is NOT a parity case: its Hann-windowed spectrum is flat up to rounding, so the strict
+    # 3-point peak test of psychoac.py:162 is decided by the last bits of whichever FFT is used -- the
+    # reference's own result there depends on its NumPy version.  See DESIGN.md "Ill-conditioned inputs".)
     from mrcaudiocodec_amd import synth
     sil = np.zeros(2048)
     sq = np.where((np.arange(2048) // 24) % 2 == 0, 1.0, -1.0) * (32767 * 2.0 / 65535)
-    imp = np.zeros(2048); imp[1500] = 0.9
+    nn = np.arange(2048)
+    imp = synth.pcm_to_float(np.rint(20000 * np.exp(-((nn - 1500) / 200.0) ** 2) *
+                                     (np.sin(0.11 * nn) + 0.5 * np.sin(0.83 * nn))))
     sine = synth.c1_sine(2)[1024:3072]
     blocks = np.stack([sil, sq, imp, sine])
     got = h.encode_mono(blocks, 1024, 1024, want_mdct=True)
