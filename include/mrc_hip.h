@@ -148,6 +148,11 @@ int mrc_dev_encode(mrc_handle* h, int a, int b, int64_t n_frames, const double* 
 /* Per-stage device time of the most recent mrc_dev_encode / stage call when timing is enabled
  * (hipEvents on the launch stream; the call then synchronises).  ms[0..2] = mdct, smr, alloc+quant. */
 int mrc_set_timing(mrc_handle* h, int enabled);
+/* Options.  MRC_OPT_EXACT_SPREAD = 1: evaluate the masker spreading (psychoac.py:68-78) with the
+ * reference's own expression and pow() per (masker, line) instead of the factored fast form (default 0).
+ * Both give the same integer outputs on the parity corpora; the exact form is ~8x slower. */
+#define MRC_OPT_EXACT_SPREAD 1
+int mrc_set_option(mrc_handle* h, int option, int value);
 int mrc_get_stage_ms(mrc_handle* h, double* ms /*[3]*/);
 
 #ifdef __cplusplus

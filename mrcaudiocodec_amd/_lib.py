@@ -80,6 +80,7 @@ def _load():
         "mrc_dev_encode": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64] +
                            [C.c_void_p] * 10),
         "mrc_set_timing": (C.c_int, [H, C.c_int]),
+        "mrc_set_option": (C.c_int, [H, C.c_int, C.c_int]),
         "mrc_get_stage_ms": (C.c_int, [H, _f64p]),
     }
     for name, (res, args) in sig.items():
@@ -287,6 +288,9 @@ class Handle:
         self._check(lib.mrc_dev_alloc_quant(self._h, a, b, n_frames, int(joint), lines, overall_scale, smr,
                                             reservoir_in, ms_switch, bit_alloc, scale_factor, mantissa,
                                             reservoir_out, stream))
+
+    def set_option(self, option, value):
+        self._check(lib.mrc_set_option(self._h, int(option), int(value)))
 
     def set_timing(self, on):
         self._check(lib.mrc_set_timing(self._h, int(bool(on))))

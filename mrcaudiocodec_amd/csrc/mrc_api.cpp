@@ -45,6 +45,7 @@ struct mrc_handle {
     // staging of the host entry points
     DevBuf inL, inR, inAux, inAux2, inAux3, outA, outB, outC, outD, outE, outF, outG;
     bool timing = false;
+    bool exactSpread = false;        // mrc_set_option(MRC_OPT_EXACT_SPREAD)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     double stageMs[3] = {0, 0, 0};
 };
@@ -188,6 +189,12 @@ int mrc_set_timing(mrc_handle* h, int enabled) {
     return MRC_OK;
 }
 
+int mrc_set_option(mrc_handle* h, int option, int value) {
+    if (!h) return MRC_ERR_INVALID;
+    if (option == MRC_OPT_EXACT_SPREAD) { h->exactSpread = value != 0; return MRC_OK; }
+    return fail(h, MRC_ERR_INVALID, "mrc_set_option: unknown option");
+}
+
 int mrc_get_stage_ms(mrc_handle* h, double* ms) {
     if (!h || !ms) return MRC_ERR_INVALID;
     for (int i = 0; i < 3; ++i) ms[i] = h->stageMs[i];
@@ -217,7 +224,7 @@ int mrc_dev_smr(mrc_handle* h, int a, int b, int64_t n_frames, const double* ch_
     int rc = get_shape(h, a, b, &hs);
     if (rc) return rc;
     MRC_HIP(h, launch_smr(hs->dev, n_frames, ch_left, ch_right, frame_stride, offsets, lines, overall_scale, smr,
-                          thresh, pick_stream(h, stream)));
+                          thresh, h->exactSpread, pick_stream(h, stream)));
     return MRC_OK;
 }
 
@@ -261,7 +268,7 @@ int mrc_dev_encode(mrc_handle* h, int a, int b, int64_t n_frames, const double* 
     if (h->timing) MRC_HIP(h, hipEventRecord(h->ev[0], st));
     MRC_HIP(h, launch_mdct(S, n_frames, ch_left, ch_right, frame_stride, offsets, true, lines, overall_scale, st));
     if (h->timing) MRC_HIP(h, hipEventRecord(h->ev[1], st));
-    MRC_HIP(h, launch_smr(S, n_frames, ch_left, ch_right, frame_stride, offsets, lines, overall_scale, smr, nullptr, st));
+    MRC_HIP(h, launch_smr(S, n_frames, ch_left, ch_right, frame_stride, offsets, lines, overall_scale, smr, nullptr, h->exactSpread, st));
     if (h->timing) MRC_HIP(h, hipEventRecord(h->ev[2], st));
     MRC_HIP(h, launch_alloc_quant(S, n_frames, joint, lines, overall_scale, smr, reservoir_in, ms_switch, bit_alloc,
                                   scale_factor, mantissa, reservoir_out, st));
@@ -417,7 +424,7 @@ int mrc_smr(mrc_handle* h, int64_t n, int a, int b, const double* blocks, const 
                                h->outA.as<int>(), h->stream));
     }
     MRC_HIP(h, launch_smr(S, n, h->inL.as<double>(), nullptr, S.N, nullptr, h->outG.as<double>(), h->outA.as<int>(),
-                          h->outC.as<double>(), thresh ? h->outE.as<double>() : nullptr, h->stream));
+                          h->outC.as<double>(), thresh ? h->outE.as<double>() : nullptr, h->exactSpread, h->stream));
     MRC_TRY(s.down(smr, h->outC, szSmr));
     if (thresh) MRC_TRY(s.down(thresh, h->outE, szLines));
     MRC_HIP(h, hipStreamSynchronize(h->stream));

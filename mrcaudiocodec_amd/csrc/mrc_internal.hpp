@@ -62,7 +62,7 @@ hipError_t launch_unscale(int64_t nBlocks, int halfN, const double* scaled, cons
                           hipStream_t st);
 hipError_t launch_smr(const DevShape& S, int64_t nFrames, const double* chL, const double* chR,
                       int64_t stride, const int64_t* offsets, const double* lines, const int* oscale,
-                      double* smr, double* thresh, hipStream_t st);
+                      double* smr, double* thresh, bool exactSpread, hipStream_t st);
 hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, const double* lines,
                               const int* oscale, const double* smr, const int* resIn, int* msSwitch,
                               int* bitAlloc, int* scaleFactor, int* mantissa, int* resOut, hipStream_t st);

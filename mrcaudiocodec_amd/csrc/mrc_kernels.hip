@@ -205,7 +205,34 @@ __global__ __launch_bounds__(kThreads) void mdct_kernel(DevShape S, int nsig, co
 // SMR: one workgroup per (frame, signal)
 // ------------------------------------------------------------------------------------------------
 constexpr int kLinesPerThread = 4;                     // register tile: kThreads*4 = 1024 lines per sweep
+constexpr double kLog2Of10 = 3.32192809488736234787;
+constexpr double kLowerSlopeBits = -2.7 * 3.32192809488736234787;   // -27 dB/Bark below the masker (psychoac.py:74)
 
+// 2^t for finite t (any sign; used with t <= 0): k = rint(t), 2^(t-k) by a degree-11 polynomial on
+// [-0.5, 0.5] (Chebyshev-node fit, max relative error 2e-16 incl. evaluation), scaled by 2^k.
+// t == 0 returns exactly 1, so a line inside +-0.5 Bark gets exactly the masker's own intensity.
+__device__ __forceinline__ double exp2_neg(double t) {
+    const double k = rint(t);
+    const double f = t - k;
+    double p = 0x1.e9ec1fcb69a7fp-32;
+    p = fma(p, f, 0x1.e6228acd1c6e5p-28);
+    p = fma(p, f, 0x1.b524ebd13a55fp-24);
+    p = fma(p, f, 0x1.62bfc2c86d700p-20);
+    p = fma(p, f, 0x1.ffcbfc6da6ed1p-17);
+    p = fma(p, f, 0x1.430913112c61bp-13);
+    p = fma(p, f, 0x1.5d87fe78a3f9cp-10);
+    p = fma(p, f, 0x1.3b2ab6fb9f1a5p-7);
+    p = fma(p, f, 0x1.c6b08d704a0c6p-5);
+    p = fma(p, f, 0x1.ebfbdff82c5aep-3);
+    p = fma(p, f, 0x1.62e42fefa39efp-1);
+    p = fma(p, f, 1.0);
+    return ldexp(p, (int)k);
+}
+
+// EXACT = true keeps the reference's per-(masker, line) expression with pow(); EXACT = false (default)
+// evaluates the same quantity factored as I_m * 2^(slope_m * u): ~8x fewer instructions, same integers
+// on every parity corpus (tests/test_gpu_parity.py::test_spread_modes_agree).
+template <bool EXACT>
 __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, const double* __restrict__ chL,
                                                        const double* __restrict__ chR, int64_t stride,
                                                        const int64_t* __restrict__ offsets,
@@ -246,9 +273,11 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
     __syncthreads();                                    // T (in A or B) is dead from here on
 
     // tonal maskers: strict 3-point peaks at bins p = 1 .. last-2, kept in increasing bin order
-    double* mLvl = smem;                                // level - 15 dB        (aliases A)
-    double* mZ = mLvl + H / 2 + 1;                      // Bark position
-    double* mBoost = mZ + H / 2 + 1;                    // 0.37*max(level-40,0)
+    // per masker: [0] level-15 dB (EXACT mode) or its intensity 10^((level-15-96)/10) (fast mode),
+    //             [1] Bark position, [2] 0.37*max(level-40,0) (EXACT) or the upper slope in bits per Bark (fast)
+    double* mLvl = smem;                                // (aliases A)
+    double* mZ = mLvl + H / 2 + 1;
+    double* mBoost = mZ + H / 2 + 1;
     const int nCand = last - 2;
     const int per = (nCand + kThreads - 1) / kThreads;
     const int p0 = 1 + tid * per;
@@ -271,8 +300,15 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
             double fm = S.binHz * (((p - 1) * x0 + p * x1) + (p + 1) * x2) / s3;   // psychoac.py:165
             double q = fm / 7500.;
             mZ[before] = 13 * atan(0.76 * fm / 1000.) + 3.5 * atan(q * q);   // psychoac.py:27-29
-            mLvl[before] = level - 15.0;                                     // psychoac.py:42-43 (tonal drop)
-            mBoost[before] = 0.37 * fmax(level - 40, 0.0);                   // psychoac.py:76
+            const double lvl15 = level - 15.0;                               // psychoac.py:42-43 (tonal drop)
+            const double boost = 0.37 * fmax(level - 40, 0.0);               // psychoac.py:76
+            if (EXACT) {
+                mLvl[before] = lvl15;
+                mBoost[before] = boost;
+            } else {
+                mLvl[before] = pow(10.0, (lvl15 - 96) / 10);                 // value inside +-0.5 Bark, psychoac.py:14-18
+                mBoost[before] = ((-27 + boost) / 10) * kLog2Of10;           // dB/Bark above the masker -> bits/Bark
+            }
             ++before;
         }
     }
@@ -296,12 +332,18 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
 #pragma unroll
             for (int j = 0; j < kLinesPerThread; ++j) {
                 double dz = z[j] - zm;
-                double adz = fabs(dz);
-                double t = adz - 0.5;
-                double arg = lvl;
-                if (adz > 0.5) arg = lvl + (-27 * t);
-                if (dz > 0.5) arg = arg + boost * t;
-                tot[j] += pow(10.0, (arg - 96) / 10);
+                if (EXACT) {                             // the reference's expression, operation by operation
+                    double adz = fabs(dz);
+                    double t = adz - 0.5;
+                    double arg = lvl;
+                    if (adz > 0.5) arg = lvl + (-27 * t);
+                    if (dz > 0.5) arg = arg + boost * t;
+                    tot[j] += pow(10.0, (arg - 96) / 10);
+                } else {                                 // same quantity as I_m * 2^(slope * max(|dz|-0.5, 0))
+                    double u = fmax(fabs(dz) - 0.5, 0.0);
+                    double slope = dz > 0.0 ? boost : kLowerSlopeBits;
+                    tot[j] = fma(lvl, exp2_neg(slope * u), tot[j]);
+                }
             }
         }
 #pragma unroll
@@ -563,12 +605,16 @@ hipError_t launch_unscale(int64_t nBlocks, int halfN, const double* scaled, cons
 
 hipError_t launch_smr(const DevShape& S, int64_t nFrames, const double* chL, const double* chR, int64_t stride,
                       const int64_t* offsets, const double* lines, const int* oscale, double* smr, double* thresh,
-                      hipStream_t st) {
+                      bool exactSpread, hipStream_t st) {
     if (nFrames <= 0) return hipSuccess;
     const int nsig = chR ? 4 : 1;
     size_t lds = (size_t)(5 * S.H) * sizeof(double);
-    hipLaunchKernelGGL(smr_kernel, dim3((unsigned)(nFrames * nsig)), dim3(kThreads), lds, st, S, nsig, chL, chR,
-                       stride, offsets, lines, oscale, smr, thresh);
+    if (exactSpread)
+        hipLaunchKernelGGL(smr_kernel<true>, dim3((unsigned)(nFrames * nsig)), dim3(kThreads), lds, st, S, nsig, chL,
+                           chR, stride, offsets, lines, oscale, smr, thresh);
+    else
+        hipLaunchKernelGGL(smr_kernel<false>, dim3((unsigned)(nFrames * nsig)), dim3(kThreads), lds, st, S, nsig, chL,
+                           chR, stride, offsets, lines, oscale, smr, thresh);
     return hipGetLastError();
 }
 

@@ -135,6 +135,24 @@ def test_encode_joint_ms_long(h):
     assert np.abs(got["mdct"] - ref["mdct"]).max() <= MDCT_RTOL * np.abs(ref["mdct"]).max()
 
 
+def test_spread_modes_agree(h):
+    # MRC_OPT_EXACT_SPREAD: the reference's own per-(masker, line) expression with pow() vs the default
+    # factored form I_m * 2^(slope*u).  Same integers; thresholds within 1e-10 dB of each other.
+    from mrcaudiocodec_amd import synth
+    blocks = np.array(fast.blocks_from_stream(synth.c2_noise(256, seed=77), 1024))
+    fast_out = h.encode_mono(blocks, 1024, 1024)
+    thr_fast = h.smr(blocks[:32], 1024, 1024, want_thresh=True)[1]
+    h.set_option(1, 1)
+    try:
+        exact_out = h.encode_mono(blocks, 1024, 1024)
+        thr_exact = h.smr(blocks[:32], 1024, 1024, want_thresh=True)[1]
+    finally:
+        h.set_option(1, 0)
+    _assert_int_parity(fast_out, exact_out)
+    _assert_int_parity(exact_out, fast.encode_mono_batch(blocks, 1024, 1024))
+    assert np.abs(thr_fast - thr_exact).max() <= 1e-10
+
+
 @pytest.mark.parametrize("ab", SHAPES[1:])
 def test_encode_short_and_transition(h, ab):
     a, b = ab
