@@ -57,6 +57,11 @@ int scale_factor_host(double v, int nScaleBits, int nMantBits);
 hipError_t launch_mdct(const DevShape& S, int64_t nFrames, const double* chL, const double* chR,
                        int64_t stride, const int64_t* offsets, bool applyWindow, double* lines, int* oscale,
                        hipStream_t st);
+// mrc_kernels_long.hip -- long-block specialisation (a = b = 1024)
+bool mdct_long_applicable(const DevShape& S, int64_t stride, const int64_t* offsets, const double* chL,
+                          const double* chR);
+hipError_t launch_mdct_long(const DevShape& S, int64_t nFrames, const double* chL, const double* chR,
+                            int64_t stride, double* lines, int* oscale, hipStream_t st);
 hipError_t launch_window(const DevShape& S, int64_t nBlocks, const double* in, double* out, hipStream_t st);
 hipError_t launch_unscale(int64_t nBlocks, int halfN, const double* scaled, const int* oscale, double* lines,
                           hipStream_t st);

@@ -1,0 +1,240 @@
+// Long-block (a = b = 1024, N = 2048) specialisation of the windowed MDCT for gfx950.
+//
+// One 64-lane wavefront owns one (frame, signal) at a time and walks a run of consecutive units, so a
+// hop that two consecutive frames share is fetched from HBM once and from L2 the second time.  The
+// 512-point complex FFT inside the N/4 MDCT algorithm is three radix-8 Stockham passes: 8 points per
+// lane in registers, two lane exchanges through LDS (the first one padded by one slot per 8 so that the
+// stride-8 writes stay conflict-free), no workgroup barrier anywhere -- only wave-local ordering.
+// Window values and inter-pass twiddles of a lane never change from frame to frame and live in
+// registers; pre-/post-twiddles sit in LDS, shared by the four waves of the workgroup.
+// HBM traffic per unit is the algorithmic 8 KiB in + 8 KiB out: loads are 16 B per lane over 1 KiB
+// contiguous, stores likewise after an LDS transpose of the even/odd output interleave.
+//
+// Arithmetic: same formulas as the generic mdct_kernel (window.py:104-121, mdct.py:63-76,
+// codecThem.py:321-322), float64, file compiled with -ffp-contract=off.
+#include "mrc_internal.hpp"
+
+namespace mrc {
+namespace {
+
+constexpr int kWave = 64;
+constexpr int kWavesPerBlock = 4;
+constexpr int kM = 1024, kQ = 512;                 // N = 2048: N/2 lines, N/4-point FFT
+constexpr int kWaveLds = 2048;                       // doubles per wave (16 KiB)
+constexpr int kRun = 16;                             // consecutive units per wave
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }     // a * (-i)
+
+// LDS traffic between lanes of ONE wave: order the wave's own DS operations and stop the compiler from
+// moving LDS accesses across this point.  No other wave is involved.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// 4-point DFT (forward): v -> natural order
+__device__ __forceinline__ void dft4(double2 v0, double2 v1, double2 v2, double2 v3, double2* o0, double2* o1,
+                                     double2* o2, double2* o3) {
+    double2 s0 = cadd(v0, v2), s1 = csub(v0, v2), s2 = cadd(v1, v3), s3 = mul_mi(csub(v1, v3));
+    *o0 = cadd(s0, s2);
+    *o1 = cadd(s1, s3);
+    *o2 = csub(s0, s2);
+    *o3 = csub(s1, s3);
+}
+
+// 8-point DFT (forward, e^{-2 pi i/8}), in place, natural order out
+__device__ __forceinline__ void dft8(double2* u) {
+    const double h = 0.70710678118654752440;
+    double2 a0 = cadd(u[0], u[4]), a1 = cadd(u[1], u[5]), a2 = cadd(u[2], u[6]), a3 = cadd(u[3], u[7]);
+    double2 b0 = csub(u[0], u[4]), b1 = csub(u[1], u[5]), b2 = csub(u[2], u[6]), b3 = csub(u[3], u[7]);
+    b1 = make_double2(h * (b1.x + b1.y), h * (b1.y - b1.x));          // * (1 - i)/sqrt2
+    b2 = mul_mi(b2);                                                  // * (-i)
+    b3 = make_double2(h * (b3.y - b3.x), -h * (b3.x + b3.y));         // * (-1 - i)/sqrt2
+    dft4(a0, a1, a2, a3, &u[0], &u[2], &u[4], &u[6]);
+    dft4(b0, b1, b2, b3, &u[1], &u[3], &u[5], &u[7]);
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+
+__device__ __forceinline__ int scale_factor20(double v, int nScaleBits) {        // quantize.py:114-146, nMantBits = 5
+    const int cap = (1 << nScaleBits) - 1;
+    const int nBits = cap + 5;
+    double mag = fabs(v);
+    long long code = mag >= 1.0 ? (1LL << (nBits - 1)) - 1
+                                : (long long)((((double)((1LL << nBits) - 1)) * mag + 1.0) / 2.0);
+    int top = code > 0 ? 63 - __clzll(code) : 0;
+    int lz = (nBits - 2) - top;
+    return lz < cap ? lz : cap;
+}
+
+template <int NSIG>
+__device__ __forceinline__ void load_pair(const double* __restrict__ L, const double* __restrict__ R, int64_t i, int sig,
+                                          double* e, double* o) {
+    if (NSIG == 1 || sig == 0) {
+        double2 v = *reinterpret_cast<const double2*>(L + i);
+        *e = v.x; *o = v.y;
+    } else if (sig == 1) {
+        double2 v = *reinterpret_cast<const double2*>(R + i);
+        *e = v.x; *o = v.y;
+    } else {
+        double2 l = *reinterpret_cast<const double2*>(L + i);
+        double2 r = *reinterpret_cast<const double2*>(R + i);
+        if (sig == 2) { *e = (l.x + r.x) / 2.0; *o = (l.y + r.y) / 2.0; }       // codecThem.py:363
+        else { *e = (l.x - r.x) / 2.0; *o = (l.y - r.y) / 2.0; }                // codecThem.py:364
+    }
+}
+
+template <int NSIG>
+__global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void mdct_long_kernel(
+    DevShape S, int64_t nUnits, const double* __restrict__ chL, const double* __restrict__ chR, int64_t stride,
+    const int64_t* __restrict__ offsets, double* __restrict__ lines, int* __restrict__ oscale) {
+    __shared__ __attribute__((aligned(16))) double smem[kWavesPerBlock * kWaveLds + 4 * kQ];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    double* ws = smem + wave * kWaveLds;                               // this wave's 16 KiB
+    double2* preL = reinterpret_cast<double2*>(smem + kWavesPerBlock * kWaveLds);   // [512]
+    double2* postL = preL + kQ;                                        // [512]
+    for (int i = threadIdx.x; i < kQ; i += kWave * kWavesPerBlock) {
+        preL[i] = S.pre[i];
+        postL[i] = S.post[i];
+    }
+    // lane-constant registers: window at the lane's sample pairs, twiddles of passes 2 and 3
+    double wE[16], wO[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        double2 w = *reinterpret_cast<const double2*>(S.win + 2 * (lane + 64 * c));
+        wE[c] = w.x; wO[c] = w.y;
+    }
+    double2 tw2[7], tw3[7];
+#pragma unroll
+    for (int r = 1; r < 8; ++r) {
+        tw2[r - 1] = S.wQ[8 * (lane & 7) * r];                         // W512^(8 k r), k = lane % 8
+        tw3[r - 1] = S.wQ[lane * r];                                   // W512^(lane r)
+    }
+    __syncthreads();                                                   // pre/post tables visible to all waves
+
+    const int64_t firstUnit = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * kRun;
+    for (int it = 0; it < kRun; ++it) {
+        const int64_t unit = firstUnit + it;
+        if (unit >= nUnits) break;                                     // wave-uniform
+        const int64_t f = NSIG == 1 ? unit : unit / NSIG;
+        const int sig = NSIG == 1 ? 0 : (int)(unit % NSIG);
+        const int64_t off = offsets ? offsets[f] : f * stride;
+
+        // ---- A. coalesced load (16 B per lane), window, de-interleave into yE / yO
+        double* yE = ws;
+        double* yO = ws + kM;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const int i = lane + 64 * c;
+            double e, o;
+            load_pair<NSIG>(chL, chR, off + 2 * i, sig, &e, &o);
+            yE[i] = e * wE[c];
+            yO[i] = o * wO[c];
+        }
+        wave_sync();
+        // ---- B. fold N -> N/2 -> 512 complex points (n = lane + 64 r), pre-twiddle
+        double2 u[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int n = lane + 64 * r;
+            double re, im;
+            if (r < 4) {           // n < 256
+                re = -yO[767 - n] - yE[768 + n];
+                im = yO[255 - n] - yE[256 + n];
+            } else {
+                re = yE[n - 256] - yO[767 - n];
+                im = -yE[256 + n] - yO[1279 - n];
+            }
+            u[r] = cmul(make_double2(re, im), preL[n]);
+        }
+        wave_sync();               // all gathers done before the region is reused
+        // ---- C. FFT-512 = 8 x 8 x 8
+        dft8(u);
+        double2* ex = reinterpret_cast<double2*>(ws);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) ex[9 * lane + q] = u[q];           // element 8*lane+q, padded (+1 per 8)
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) u[r] = ex[lane + (lane >> 3) + 72 * r];   // element lane + 64 r
+        wave_sync();
+#pragma unroll
+        for (int r = 1; r < 8; ++r) u[r] = cmul(u[r], tw2[r - 1]);
+        dft8(u);
+        {
+            const int base = 64 * (lane >> 3) + (lane & 7);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) ex[base + 8 * q] = u[q];
+        }
+        wave_sync();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) u[r] = ex[lane + 64 * r];
+        wave_sync();
+#pragma unroll
+        for (int r = 1; r < 8; ++r) u[r] = cmul(u[r], tw3[r - 1]);
+        dft8(u);                                                        // u[q] = T[lane + 64 q]
+        // ---- D. post-twiddle, X[2k] = (2/N) Re, X[N/2-1-2k] = -(2/N) Im, transpose through LDS
+        double* xE = ws;                                                // xE[i] = X[2i]
+        double* xO = ws + kQ;                                           // xO[i] = X[2i+1]
+        double peak = 0.0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = lane + 64 * q;
+            double2 c = cmul(u[q], postL[k]);
+            double a = S.twoOverN * c.x;
+            double b = S.twoOverN * (-c.y);
+            xE[k] = a;
+            xO[511 - k] = b;                                            // line 1023-2k = 2*(511-k)+1
+            peak = fmax(peak, fmax(fabs(a), fabs(b)));
+        }
+        wave_sync();
+        double* dst = lines + unit * kM;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int i = lane + 64 * c;
+            *reinterpret_cast<double2*>(dst + 2 * i) = make_double2(xE[i], xO[i]);
+        }
+        peak = wave_max(peak);
+        if (lane == 0) oscale[unit] = scale_factor20(peak, S.nScaleBits);    // codecThem.py:321-322
+        wave_sync();               // output staging read before the next unit overwrites the region
+    }
+}
+
+}  // namespace
+
+bool mdct_long_applicable(const DevShape& S, int64_t stride, const int64_t* offsets, const double* chL,
+                          const double* chR) {
+    if (S.a != 1024 || S.b != 1024) return false;
+    if (offsets) return false;                       // offsets may be odd: 16-byte loads need even sample offsets
+    if (stride % 2 != 0) return false;
+    if ((reinterpret_cast<uintptr_t>(chL) & 15) || (chR && (reinterpret_cast<uintptr_t>(chR) & 15))) return false;
+    return true;
+}
+
+hipError_t launch_mdct_long(const DevShape& S, int64_t nFrames, const double* chL, const double* chR, int64_t stride,
+                            double* lines, int* oscale, hipStream_t st) {
+    if (nFrames <= 0) return hipSuccess;
+    const int nsig = chR ? 4 : 1;
+    const int64_t nUnits = nFrames * nsig;
+    const int64_t perBlock = (int64_t)kWavesPerBlock * kRun;
+    const unsigned grid = (unsigned)((nUnits + perBlock - 1) / perBlock);
+    if (nsig == 1)
+        hipLaunchKernelGGL(mdct_long_kernel<1>, dim3(grid), dim3(kWave * kWavesPerBlock), 0, st, S, nUnits, chL, chR,
+                           stride, nullptr, lines, oscale);
+    else
+        hipLaunchKernelGGL(mdct_long_kernel<4>, dim3(grid), dim3(kWave * kWavesPerBlock), 0, st, S, nUnits, chL, chR,
+                           stride, nullptr, lines, oscale);
+    return hipGetLastError();
+}
+
+}  // namespace mrc
