@@ -1,0 +1,134 @@
+// Device-side helpers shared by the gfx950 kernels (included by the .hip files only).
+#pragma once
+#include "mrc_internal.hpp"
+
+namespace mrc {
+namespace dev {
+
+constexpr int kThreads = 256;
+constexpr int kWave = 64;
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// The four signals of a joint block: L, R, M=(L+R)/2, S=(L-R)/2 (codecThem.py:363-364).
+__device__ __forceinline__ double load_signal(const double* __restrict__ L, const double* __restrict__ R,
+                                               int64_t i, int sig) {
+    if (sig == 0) return L[i];
+    if (sig == 1) return R[i];
+    double l = L[i], r = R[i];
+    return sig == 2 ? (l + r) / 2.0 : (l - r) / 2.0;
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+
+// psychoac.py:8-12
+__device__ __forceinline__ double spl_db(double intensity) {
+    return fmax(96 + 10 * log10(intensity), -30.0);
+}
+
+// quantize.py:12-38 magnitude code for |x| (R = nBits)
+__device__ __forceinline__ long long mag_code(double mag, int nBits) {
+    if (mag >= 1.0) return (1LL << (nBits - 1)) - 1;
+    return (long long)((((double)((1LL << nBits) - 1)) * mag + 1.0) / 2.0);
+}
+
+// quantize.py:114-146
+__device__ __forceinline__ int scale_factor_dev(double v, int nScaleBits, int nMantBits) {
+    const int cap = (1 << nScaleBits) - 1;
+    const int nBits = cap + nMantBits;
+    long long code = mag_code(fabs(v), nBits);
+    int top = code > 0 ? 63 - __clzll(code) : 0;
+    int lz = (nBits - 2) - top;
+    return lz < cap ? lz : cap;
+}
+
+// quantize.py:294-322 (one element)
+__device__ __forceinline__ int mantissa_dev(double x, int scale, int nScaleBits, int nMantBits) {
+    const int cap = (1 << nScaleBits) - 1;
+    const int nBits = cap + nMantBits;
+    long long code = mag_code(fabs(x), nBits);
+    int shift = cap - scale;
+    if (shift < 0) shift = 0;
+    long long m = code >> shift;
+    return (int)((x < 0.0 ? (1LL << (nMantBits - 1)) : 0LL) + m);
+}
+
+// ------------------------------------------------------------------------------------------------
+// mixed-radix Stockham autosort FFT in LDS (forward, e^{-i...}); all threads of the block take part
+// ------------------------------------------------------------------------------------------------
+template <int R> __device__ __forceinline__ void butterfly(double2* u);
+
+template <> __device__ __forceinline__ void butterfly<2>(double2* u) {
+    double2 a = u[0], b = u[1];
+    u[0] = make_double2(a.x + b.x, a.y + b.y);
+    u[1] = make_double2(a.x - b.x, a.y - b.y);
+}
+
+template <> __device__ __forceinline__ void butterfly<3>(double2* u) {
+    const double c = 0.86602540378443864676;            // sqrt(3)/2
+    double2 t = make_double2(u[1].x + u[2].x, u[1].y + u[2].y);
+    double2 d = make_double2(u[1].x - u[2].x, u[1].y - u[2].y);
+    double2 m = make_double2(u[0].x - 0.5 * t.x, u[0].y - 0.5 * t.y);
+    u[0] = make_double2(u[0].x + t.x, u[0].y + t.y);
+    u[1] = make_double2(m.x + c * d.y, m.y - c * d.x);
+    u[2] = make_double2(m.x - c * d.y, m.y + c * d.x);
+}
+
+template <> __device__ __forceinline__ void butterfly<4>(double2* u) {
+    double2 a = make_double2(u[0].x + u[2].x, u[0].y + u[2].y);
+    double2 b = make_double2(u[0].x - u[2].x, u[0].y - u[2].y);
+    double2 c = make_double2(u[1].x + u[3].x, u[1].y + u[3].y);
+    double2 d = make_double2(u[1].x - u[3].x, u[1].y - u[3].y);
+    u[0] = make_double2(a.x + c.x, a.y + c.y);
+    u[1] = make_double2(b.x + d.y, b.y - d.x);
+    u[2] = make_double2(a.x - c.x, a.y - c.y);
+    u[3] = make_double2(b.x - d.y, b.y + d.x);
+}
+
+template <int R>
+__device__ __forceinline__ void fft_pass(const double2* __restrict__ in, double2* __restrict__ out, int n, int p,
+                                         const double2* __restrict__ W, int tid) {
+    const int T = n / R;
+    const int tws = n / (p * R);
+    for (int i = tid; i < T; i += kThreads) {
+        const int k = i % p;
+        const int j = (i / p) * (p * R) + k;
+        double2 u[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            u[r] = in[i + r * T];
+            if (r > 0) u[r] = cmul(u[r], W[k * r * tws]);
+        }
+        butterfly<R>(u);
+#pragma unroll
+        for (int q = 0; q < R; ++q) out[j + q * p] = u[q];
+    }
+}
+
+// Runs all passes; returns the buffer (A or B) that holds the natural-order result.
+__device__ double2* fft_lds(double2* A, double2* B, int n, const int* rad, int nrad, const double2* __restrict__ W,
+                            int tid) {
+    int p = 1;
+    for (int s = 0; s < nrad; ++s) {
+        const int R = rad[s];
+        if (R == 4) fft_pass<4>(A, B, n, p, W, tid);
+        else if (R == 2) fft_pass<2>(A, B, n, p, W, tid);
+        else fft_pass<3>(A, B, n, p, W, tid);
+        __syncthreads();
+        double2* t = A; A = B; B = t;
+        p *= R;
+    }
+    return A;
+}
+
+}  // namespace dev
+}  // namespace mrc

@@ -37,6 +37,7 @@ struct DevShape {
     const double2* wN;               // [H] exp(-2 pi i k/N)
     const double* zb;                // [halfN] Bark(MDCTFreq) (psychoac.py:27-29,142-143)
     const double* quiet;             // [halfN] Intensity(Thresh(MDCTFreq)) (psychoac.py:155)
+    const double* lowE;              // [halfN] 2^(2.7 log2(10) (zb+1/2)): per-line factor of the -27 dB/Bark lower slope
     const int* bandLo;               // [nBands]
     const int* bandN;                // [nBands]
     const unsigned char* bandOfLine; // [halfN]

@@ -1,0 +1,322 @@
+// smr_kernel -- psychoac.py:134-219 on gfx950: Hann window -> real FFT -> intensity spectrum -> tonal
+// maskers (strict 3-point peaks, kept in bin order) -> masked threshold on the MDCT line grid ->
+// SMR per scale-factor band.  One 256-thread workgroup per (frame, signal), any block shape.
+//
+// The cost is the spreading (psychoac.py:68-78,166-168): ~P maskers x N/2 lines of 10^x in float64
+// (P ~ 257, N/2 = 1024 on white noise).  Two evaluation modes:
+//
+//  EXACT = true   the reference's expression, operation by operation, pow() per (masker, line), summed
+//                 in masker order.  ~200 fp64 instructions per pair.
+//  EXACT = false  (default) "sorted sweep".  Lines and maskers are both sorted in Bark, so for a line k
+//                 the maskers split into a prefix {z_m <= z_k + 1/2} and a suffix {z_m > z_k + 1/2}:
+//                   prefix: I_m * 2^(s_m * max(z_k - z_m - 1/2, 0)), s_m the level-dependent upper slope in
+//                           bits/Bark; one degree-11 polynomial 2^f per pair, exactly I_m inside +-1/2 Bark;
+//                   suffix: the lower slope is the same -27 dB/Bark for every masker, so the sum factors:
+//                           2^(-b(z_k+1/2)) * sum_{m in suffix} I_m 2^(b z_m), b = -2.7 log2(10): one table
+//                           value per line times a suffix sum over maskers (exponents carried in
+//                           double-double so the large cancelling exponents cost no accuracy).
+//                 ~20 fp64 instructions per pair that needs 2^x, one add per in-band pair, nothing per
+//                 suffix pair; each wave sweeps contiguous 64-line chunks with wave-uniform loop bounds.
+//                 Same integers as EXACT on every parity corpus, thresholds within 1e-10 dB
+//                 (tests/test_gpu_parity.py::test_spread_modes_agree).
+#include "mrc_device.hpp"
+
+namespace mrc {
+using namespace dev;
+namespace {
+
+constexpr int kLinesPerThread = 4;                     // EXACT mode register tile
+constexpr double kLog2Of10 = 0x1.a934f0979a371p+1;
+// b = -2.7*log2(10) bits per Bark below the masker (psychoac.py:74), split hi + lo
+constexpr double kLowHi = -0x1.1f03bbffee7edp+3;
+constexpr double kLowLo = 0x1.e3c74df63d090p-51;
+
+// 2^f on [-0.5, 0.5]: degree-11 Chebyshev-node fit, max relative error 2e-16 including evaluation.
+__device__ __forceinline__ double exp2_poly(double f) {
+    double p = 0x1.e9ec1fcb69a7fp-32;
+    p = fma(p, f, 0x1.e6228acd1c6e5p-28);
+    p = fma(p, f, 0x1.b524ebd13a55fp-24);
+    p = fma(p, f, 0x1.62bfc2c86d700p-20);
+    p = fma(p, f, 0x1.ffcbfc6da6ed1p-17);
+    p = fma(p, f, 0x1.430913112c61bp-13);
+    p = fma(p, f, 0x1.5d87fe78a3f9cp-10);
+    p = fma(p, f, 0x1.3b2ab6fb9f1a5p-7);
+    p = fma(p, f, 0x1.c6b08d704a0c6p-5);
+    p = fma(p, f, 0x1.ebfbdff82c5aep-3);
+    p = fma(p, f, 0x1.62e42fefa39efp-1);
+    return fma(p, f, 1.0);
+}
+
+// 2^t for finite t; t == 0 gives exactly 1 (a line inside +-1/2 Bark gets exactly the masker's intensity)
+__device__ __forceinline__ double exp2_fast(double t) {
+    const double k = rint(t);
+    return ldexp(exp2_poly(t - k), (int)k);
+}
+
+// 2^(hi + lo), |lo| << 1
+__device__ __forceinline__ double exp2_dd(double hi, double lo) {
+    const double k = rint(hi);
+    return ldexp(exp2_poly((hi - k) + lo), (int)k);
+}
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        int o = __shfl_up(v, off);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+template <bool EXACT>
+__global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, const double* __restrict__ chL,
+                                                       const double* __restrict__ chR, int64_t stride,
+                                                       const int64_t* __restrict__ offsets,
+                                                       const double* __restrict__ lines,
+                                                       const int* __restrict__ oscale, double* __restrict__ smr,
+                                                       double* __restrict__ thresh) {
+    extern __shared__ double smem[];
+    __shared__ int waveCnt[kThreads / kWave];
+    const int tid = threadIdx.x;
+    const int lane = tid & (kWave - 1), wave = tid >> 6;
+    const int H = S.H, M = S.halfN;
+    const int64_t f = blockIdx.x / nsig;
+    const int sig = blockIdx.x % nsig;
+    const int64_t off = offsets ? offsets[f] : f * stride;
+    double2* A = (double2*)smem;                        // [H]
+    double2* B = A + H;                                 // [H]
+    double* xi = smem + 4 * H;                          // [H] intensity spectrum (bins < peakLast used)
+
+    // Hann window (window.py:28-45) and real FFT through an H = N/2 point complex FFT
+    for (int n = tid; n < H; n += kThreads) {
+        double e = load_signal(chL, chR, off + 2 * n, sig) * S.hann[2 * n];
+        double o = load_signal(chL, chR, off + 2 * n + 1, sig) * S.hann[2 * n + 1];
+        A[n] = make_double2(e, o);
+    }
+    __syncthreads();
+    double2* T = fft_lds(A, B, H, S.radH, S.nRadH, S.wH, tid);
+    const int last = S.peakLast;                        // bins 0 .. last-1 are inspected (psychoac.py:160)
+    for (int k = tid; k < last; k += kThreads) {
+        double2 zk = T[k];
+        double2 zc = T[(H - k) % H];
+        zc.y = -zc.y;
+        double2 ev = make_double2(0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y));
+        double2 d = make_double2(zk.x - zc.x, zk.y - zc.y);
+        double2 od = make_double2(0.5 * d.y, -0.5 * d.x);
+        double2 X = cmul(S.wN[k], od);
+        X.x += ev.x; X.y += ev.y;
+        xi[k] = 4. * (X.x * X.x + X.y * X.y) / S.xiDen;  // psychoac.py:151
+    }
+    __syncthreads();                                    // T (in A or B) is dead from here on
+
+    // tonal maskers: strict 3-point peaks at bins p = 1 .. last-2, kept in increasing bin order.
+    // Table (aliases A), 4 doubles per masker:
+    //   EXACT: {level-15 dB, Bark z, 0.37*max(level-40,0), -}
+    //   fast : {I = 10^((level-15-96)/10), Bark z, upper slope in bits/Bark, I * 2^(b z)}
+    double* mt = smem;
+    const int nCand = last - 2;
+    const int per = (nCand + kThreads - 1) / kThreads;
+    const int p0 = 1 + tid * per;
+    const int p1 = min(p0 + per, last - 1);
+    int mine = 0;
+    for (int p = p0; p < p1; ++p) mine += (xi[p] > xi[p - 1] && xi[p] > xi[p + 1]) ? 1 : 0;
+    const int incl = wave_incl_scan(mine, lane);
+    if (lane == kWave - 1) waveCnt[wave] = incl;
+    __syncthreads();
+    int before = incl - mine, nPeaks = 0;
+    for (int w = 0; w < kThreads / kWave; ++w) {
+        const int c = waveCnt[w];
+        if (w < wave) before += c;
+        nPeaks += c;
+    }
+    for (int p = p0; p < p1; ++p) {
+        double x0 = xi[p - 1], x1 = xi[p], x2 = xi[p + 1];
+        if (x1 > x0 && x1 > x2) {
+            double s3 = (x0 + x1) + x2;
+            double level = spl_db(s3);                                       // psychoac.py:164
+            double fm = S.binHz * (((p - 1) * x0 + p * x1) + (p + 1) * x2) / s3;   // psychoac.py:165
+            double q = fm / 7500.;
+            const double zm = 13 * atan(0.76 * fm / 1000.) + 3.5 * atan(q * q);     // psychoac.py:27-29
+            const double lvl15 = level - 15.0;                               // psychoac.py:42-43 (tonal drop)
+            const double boost = 0.37 * fmax(level - 40, 0.0);               // psychoac.py:76
+            double* e = mt + 4 * before;
+            e[1] = zm;
+            if (EXACT) {
+                e[0] = lvl15;
+                e[2] = boost;
+            } else {
+                const double I = pow(10.0, (lvl15 - 96) / 10);               // psychoac.py:14-18
+                const double ph = kLowHi * zm;
+                const double pl = fma(kLowHi, zm, -ph) + kLowLo * zm;
+                e[0] = I;
+                e[2] = ((-27 + boost) / 10) * kLog2Of10;
+                e[3] = I * exp2_dd(ph, pl);
+            }
+            ++before;
+        }
+    }
+    __syncthreads();
+
+    double* excess = smem + 2 * H;                      // [M] (aliases B)
+    const int scale = oscale[blockIdx.x];
+    const double* X = lines + (int64_t)blockIdx.x * M;
+
+    if (EXACT) {
+        for (int base = 0; base < M; base += kThreads * kLinesPerThread) {
+            double z[kLinesPerThread], tot[kLinesPerThread];
+#pragma unroll
+            for (int j = 0; j < kLinesPerThread; ++j) {
+                int k = base + tid + j * kThreads;
+                bool ok = k < M;
+                z[j] = ok ? S.zb[k] : 0.0;
+                tot[j] = ok ? S.quiet[k] : 0.0;
+            }
+            // psychoac.py:166-168 + 68-78: add every masker's spread intensity, in masker order
+            for (int m = 0; m < nPeaks; ++m) {
+                const double lvl = mt[4 * m], zm = mt[4 * m + 1], boost = mt[4 * m + 2];
+#pragma unroll
+                for (int j = 0; j < kLinesPerThread; ++j) {
+                    double dz = z[j] - zm;
+                    double adz = fabs(dz);
+                    double t = adz - 0.5;
+                    double arg = lvl;
+                    if (adz > 0.5) arg = lvl + (-27 * t);
+                    if (dz > 0.5) arg = arg + boost * t;
+                    tot[j] += pow(10.0, (arg - 96) / 10);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kLinesPerThread; ++j) {
+                int k = base + tid + j * kThreads;
+                if (k < M) {
+                    double thr = spl_db(tot[j]);                                 // psychoac.py:173
+                    if (thresh) thresh[(int64_t)blockIdx.x * M + k] = thr;
+                    double xs = ldexp(X[k], scale);                              // codecThem.py:323 (exact)
+                    double spl = spl_db(2. * (xs * xs) / (1. / 2.)) - 6. * scale;   // psychoac.py:212
+                    excess[k] = spl - thr;
+                }
+            }
+        }
+    } else {
+        // suffix sums of the lower-side constants: sc[m] = sum_{j >= m} I_j 2^(b z_j), sc[nPeaks] = 0
+        double* sc = xi;                                // xi is dead (all peak reads happened before the barrier)
+        if (wave == 0) {
+            constexpr int kSeg = 8;                     // kWave * kSeg = 512 >= max number of peaks (N/4)
+            double loc[kSeg];
+            double run = 0.0;
+#pragma unroll
+            for (int i = kSeg - 1; i >= 0; --i) {
+                const int m = lane * kSeg + i;
+                run += (m < nPeaks) ? mt[4 * m + 3] : 0.0;
+                loc[i] = run;
+            }
+            double higher = 0.0, carry = run;           // exclusive suffix scan of the segment totals
+#pragma unroll
+            for (int offl = 1; offl < kWave; offl <<= 1) {
+                double o = __shfl_down(carry, offl);
+                if (lane + offl < kWave) { carry += o; higher += o; }
+            }
+#pragma unroll
+            for (int i = 0; i < kSeg; ++i) {
+                const int m = lane * kSeg + i;
+                if (m < nPeaks) sc[m] = loc[i] + higher;
+            }
+            if (lane == 0) sc[nPeaks] = 0.0;
+        }
+        __syncthreads();
+
+        // Each wave sweeps 64-line chunks (one line per lane); the chunk order pairs cheap (low) with
+        // expensive (high) chunks so the four waves finish together.  Per line, the Bark-sorted maskers
+        // split into [0, nUp): more than 1/2 Bark below the line (upper slope, needs 2^x),
+        // [nUp, cnt): within +-1/2 Bark (contributes exactly I_m), [cnt, P): more than 1/2 Bark above
+        // (lower slope, served by the suffix sums).  Wave-uniform bounds over the chunk turn that into
+        // three scalar loops.
+        const int nChunks = (M + kWave - 1) / kWave;
+        const int nWaves = kThreads / kWave;
+        for (int i = 0;; ++i) {
+            const int c = i * nWaves + ((i & 1) ? (nWaves - 1 - wave) : wave);
+            if (c >= nChunks) break;
+            const int k = c * kWave + lane;
+            const int kc = min(k, M - 1);
+            const double z = S.zb[kc];
+            double tot = S.quiet[kc];
+            int cnt, nUp;
+            {
+                int lo = 0, hi = nPeaks;                // maskers with fl(z - z_m) >= -1/2
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (z - mt[4 * mid + 1] >= -0.5) lo = mid + 1; else hi = mid;
+                }
+                cnt = lo;
+                lo = 0; hi = cnt;                       // maskers with fl(z - z_m) > 1/2
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (z - mt[4 * mid + 1] > 0.5) lo = mid + 1; else hi = mid;
+                }
+                nUp = lo;
+            }
+            int mLow = cnt, mEnd = cnt, mExp = nUp;
+#pragma unroll
+            for (int offl = 32; offl > 0; offl >>= 1) {
+                mLow = min(mLow, __shfl_xor(mLow, offl));
+                mEnd = max(mEnd, __shfl_xor(mEnd, offl));
+                mExp = max(mExp, __shfl_xor(mExp, offl));
+            }
+            mLow = __builtin_amdgcn_readfirstlane(mLow);
+            mEnd = __builtin_amdgcn_readfirstlane(mEnd);
+            mExp = __builtin_amdgcn_readfirstlane(mExp);
+            const int mPlain = min(mExp, mLow);
+            // some line of the chunk is above the masker's band, every line sees the masker
+#pragma unroll 4
+            for (int m = 0; m < mPlain; ++m) {
+                const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
+                const double u = fmax((z - zm) - 0.5, 0.0);
+                tot = fma(I, exp2_fast(sl * u), tot);
+            }
+            // same, but part of the chunk lies below the masker's band (only when the chunk spans > 1 Bark)
+            for (int m = mPlain; m < mExp; ++m) {
+                const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
+                const double u = fmax((z - zm) - 0.5, 0.0);
+                tot = fma(m < cnt ? I : 0.0, exp2_fast(sl * u), tot);
+            }
+            // no line of the chunk is above the band: every line that sees the masker is inside +-1/2 Bark
+            for (int m = mExp; m < mEnd; ++m) tot += (m < cnt) ? mt[4 * m] : 0.0;
+            if (k < M) {
+                // maskers more than 1/2 Bark above the line: -27 dB/Bark for all of them
+                const double t = fma(S.lowE[k], sc[cnt], tot);
+                const double thr = spl_db(t);                                // psychoac.py:173
+                if (thresh) thresh[(int64_t)blockIdx.x * M + k] = thr;
+                const double xs = ldexp(X[k], scale);                        // codecThem.py:323 (exact)
+                const double spl = spl_db(2. * (xs * xs) / (1. / 2.)) - 6. * scale;   // psychoac.py:212
+                excess[k] = spl - thr;
+            }
+        }
+    }
+    __syncthreads();
+    // psychoac.py:216-217: SMR of a band = max over its lines
+    for (int bnd = tid; bnd < S.nBands; bnd += kThreads) {
+        const int lo = S.bandLo[bnd], n = S.bandN[bnd];
+        double best = excess[lo];
+        for (int k = 1; k < n; ++k) best = fmax(best, excess[lo + k]);
+        smr[(int64_t)blockIdx.x * S.nBands + bnd] = best;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_smr(const DevShape& S, int64_t nFrames, const double* chL, const double* chR, int64_t stride,
+                      const int64_t* offsets, const double* lines, const int* oscale, double* smr, double* thresh,
+                      bool exactSpread, hipStream_t st) {
+    if (nFrames <= 0) return hipSuccess;
+    const int nsig = chR ? 4 : 1;
+    size_t lds = (size_t)(5 * S.H) * sizeof(double);
+    if (exactSpread)
+        hipLaunchKernelGGL(smr_kernel<true>, dim3((unsigned)(nFrames * nsig)), dim3(kThreads), lds, st, S, nsig, chL,
+                           chR, stride, offsets, lines, oscale, smr, thresh);
+    else
+        hipLaunchKernelGGL(smr_kernel<false>, dim3((unsigned)(nFrames * nsig)), dim3(kThreads), lds, st, S, nsig, chL,
+                           chR, stride, offsets, lines, oscale, smr, thresh);
+    return hipGetLastError();
+}
+
+}  // namespace mrc

@@ -199,16 +199,18 @@ bool build_shape(const mrc_config& cfg, int a, int b, HostShape* out, std::strin
     std::vector<double2> wH = unit_circle(S.H, 2.0L * kPiL / S.H);
     std::vector<double2> wN = unit_circle(S.H, 2.0L * kPiL / N);
     // psychoacoustic constants on the MDCT line grid (psychoac.py:142-143,155)
-    std::vector<double> zb(S.halfN), quiet(S.halfN);
+    std::vector<double> zb(S.halfN), quiet(S.halfN), lowE(S.halfN);
+    const long double lowBits = 2.7L * log2l(10.0L);     // 27 dB/Bark (psychoac.py:74) in bits per Bark
     for (int k = 0; k < S.halfN; ++k) {
         double f = (k + 0.5) * (((double)cfg.sample_rate / S.halfN) / 2.);
         zb[k] = bark(f);
         quiet[k] = std::pow(10.0, (thresh_quiet_db(f) - 96) / 10);
+        lowE[k] = (double)powl(2.0L, lowBits * ((long double)zb[k] + 0.5L));
     }
 
     BlobWriter bw;
     size_t oWin = bw.put(win), oHann = bw.put(hann), oPre = bw.put(pre), oPost = bw.put(post);
-    size_t oWQ = bw.put(wQ), oWH = bw.put(wH), oWN = bw.put(wN), oZb = bw.put(zb), oQuiet = bw.put(quiet);
+    size_t oWQ = bw.put(wQ), oWH = bw.put(wH), oWN = bw.put(wN), oZb = bw.put(zb), oQuiet = bw.put(quiet), oLowE = bw.put(lowE);
     size_t oLo = bw.put(out->bandLo), oCnt = bw.put(out->bandN), oBol = bw.put(bandOfLine);
     void* blob = nullptr;
     if (hipMalloc(&blob, bw.bytes.size()) != hipSuccess) { *err = "hipMalloc(shape tables) failed"; return false; }
@@ -223,6 +225,7 @@ bool build_shape(const mrc_config& cfg, int a, int b, HostShape* out, std::strin
     S.wQ = (const double2*)(base + oWQ);        S.wH = (const double2*)(base + oWH);
     S.wN = (const double2*)(base + oWN);
     S.zb = (const double*)(base + oZb);         S.quiet = (const double*)(base + oQuiet);
+    S.lowE = (const double*)(base + oLowE);
     S.bandLo = (const int*)(base + oLo);        S.bandN = (const int*)(base + oCnt);
     S.bandOfLine = (const unsigned char*)(base + oBol);
     out->blob = blob;
