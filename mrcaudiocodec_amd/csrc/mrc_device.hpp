@@ -94,14 +94,17 @@ template <> __device__ __forceinline__ void butterfly<4>(double2* u) {
     u[3] = make_double2(b.x - d.y, b.y + d.x);
 }
 
-template <int R>
+// POW2: p (the product of the radices already done) is a power of two -- true until the first radix-3
+// pass, factor() puts the 3s last -- so the index split is a mask and a shift instead of div/mod.
+template <int R, bool POW2>
 __device__ __forceinline__ void fft_pass(const double2* __restrict__ in, double2* __restrict__ out, int n, int p,
                                          const double2* __restrict__ W, int tid) {
     const int T = n / R;
     const int tws = n / (p * R);
+    const int lp = 31 - __clz(p);
     for (int i = tid; i < T; i += kThreads) {
-        const int k = i % p;
-        const int j = (i / p) * (p * R) + k;
+        const int k = POW2 ? (i & (p - 1)) : (i % p);
+        const int j = (POW2 ? (i >> lp) : (i / p)) * (p * R) + k;
         double2 u[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
@@ -120,9 +123,13 @@ __device__ double2* fft_lds(double2* A, double2* B, int n, const int* rad, int n
     int p = 1;
     for (int s = 0; s < nrad; ++s) {
         const int R = rad[s];
-        if (R == 4) fft_pass<4>(A, B, n, p, W, tid);
-        else if (R == 2) fft_pass<2>(A, B, n, p, W, tid);
-        else fft_pass<3>(A, B, n, p, W, tid);
+        const bool pow2 = (p & (p - 1)) == 0;
+        if (R == 4 && pow2) fft_pass<4, true>(A, B, n, p, W, tid);
+        else if (R == 2 && pow2) fft_pass<2, true>(A, B, n, p, W, tid);
+        else if (R == 4) fft_pass<4, false>(A, B, n, p, W, tid);
+        else if (R == 2) fft_pass<2, false>(A, B, n, p, W, tid);
+        else if (pow2) fft_pass<3, true>(A, B, n, p, W, tid);
+        else fft_pass<3, false>(A, B, n, p, W, tid);
         __syncthreads();
         double2* t = A; A = B; B = t;
         p *= R;

@@ -26,6 +26,18 @@ using namespace dev;
 namespace {
 
 constexpr int kLinesPerThread = 4;                     // EXACT mode register tile
+constexpr int kMaxPeaks = 1024;                        // peaks <= (N/2-100)/2: enough for N <= 4096
+
+// Order-preserving map double -> uint64 (a < b  <=>  key(a) < key(b), -0 < +0), so that a maximum over
+// doubles can be taken with an integer LDS atomic.
+__device__ __forceinline__ unsigned long long order_key(double v) {
+    unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double order_value(unsigned long long k) {
+    unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)b);
+}
 constexpr double kLog2Of10 = 0x1.a934f0979a371p+1;
 // b = -2.7*log2(10) bits per Bark below the masker (psychoac.py:74), split hi + lo
 constexpr double kLowHi = -0x1.1f03bbffee7edp+3;
@@ -77,6 +89,8 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
                                                        double* __restrict__ thresh) {
     extern __shared__ double smem[];
     __shared__ int waveCnt[kThreads / kWave];
+    __shared__ short pkBin[kMaxPeaks];                  // peak bins in increasing order
+    __shared__ unsigned long long bandKey[kMaxBands];   // per-band running max of the excess (order-preserving key)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6;
     const int H = S.H, M = S.halfN;
@@ -87,6 +101,7 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
     double2* B = A + H;                                 // [H]
     double* xi = smem + 4 * H;                          // [H] intensity spectrum (bins < peakLast used)
 
+    if (tid < kMaxBands) bandKey[tid] = 0ull;           // below every key; visible after the first barrier
     // Hann window (window.py:28-45) and real FFT through an H = N/2 point complex FFT
     for (int n = tid; n < H; n += kThreads) {
         double e = load_signal(chL, chR, off + 2 * n, sig) * S.hann[2 * n];
@@ -129,9 +144,16 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
         if (w < wave) before += c;
         nPeaks += c;
     }
-    for (int p = p0; p < p1; ++p) {
+    // compact the peak bins first (ordered), then one masker per thread: the transcendental-heavy
+    // table entry is computed by full waves instead of the few lanes that happen to own a peak
+    for (int p = p0; p < p1; ++p)
+        if (xi[p] > xi[p - 1] && xi[p] > xi[p + 1]) pkBin[before++] = (short)p;
+    __syncthreads();
+    for (int mi = tid; mi < nPeaks; mi += kThreads) {
+        const int p = pkBin[mi];
+        const int before = mi;
         double x0 = xi[p - 1], x1 = xi[p], x2 = xi[p + 1];
-        if (x1 > x0 && x1 > x2) {
+        {
             double s3 = (x0 + x1) + x2;
             double level = spl_db(s3);                                       // psychoac.py:164
             double fm = S.binHz * (((p - 1) * x0 + p * x1) + (p + 1) * x2) / s3;   // psychoac.py:165
@@ -152,12 +174,13 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
                 e[2] = ((-27 + boost) / 10) * kLog2Of10;
                 e[3] = I * exp2_dd(ph, pl);
             }
-            ++before;
         }
     }
     __syncthreads();
 
-    double* excess = smem + 2 * H;                      // [M] (aliases B)
+    // psychoac.py:214-217: SMR of a band = max over its lines of (SPL of the line - masked threshold),
+    // accumulated with LDS integer max-atomics on an order-preserving key (initialised by the table
+    // build's barrier below)
     const int scale = oscale[blockIdx.x];
     const double* X = lines + (int64_t)blockIdx.x * M;
 
@@ -193,7 +216,7 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
                     if (thresh) thresh[(int64_t)blockIdx.x * M + k] = thr;
                     double xs = ldexp(X[k], scale);                              // codecThem.py:323 (exact)
                     double spl = spl_db(2. * (xs * xs) / (1. / 2.)) - 6. * scale;   // psychoac.py:212
-                    excess[k] = spl - thr;
+                    atomicMax(&bandKey[S.bandOfLine[k]], order_key(spl - thr));
                 }
             }
         }
@@ -265,6 +288,9 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
             mLow = __builtin_amdgcn_readfirstlane(mLow);
             mEnd = __builtin_amdgcn_readfirstlane(mEnd);
             mExp = __builtin_amdgcn_readfirstlane(mExp);
+#ifdef MRC_PROFILE_SKIP_SPREAD                  // profiling aid: everything but the spreading loops (wrong results)
+            mLow = mEnd = mExp = 0;
+#endif
             const int mPlain = min(mExp, mLow);
             // some line of the chunk is above the masker's band, every line sees the masker
 #pragma unroll 4
@@ -281,25 +307,25 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
             }
             // no line of the chunk is above the band: every line that sees the masker is inside +-1/2 Bark
             for (int m = mExp; m < mEnd; ++m) tot += (m < cnt) ? mt[4 * m] : 0.0;
-            if (k < M) {
-                // maskers more than 1/2 Bark above the line: -27 dB/Bark for all of them
-                const double t = fma(S.lowE[k], sc[cnt], tot);
-                const double thr = spl_db(t);                                // psychoac.py:173
-                if (thresh) thresh[(int64_t)blockIdx.x * M + k] = thr;
-                const double xs = ldexp(X[k], scale);                        // codecThem.py:323 (exact)
-                const double spl = spl_db(2. * (xs * xs) / (1. / 2.)) - 6. * scale;   // psychoac.py:212
-                excess[k] = spl - thr;
+            // maskers more than 1/2 Bark above the line: -27 dB/Bark for all of them
+            const double t = fma(S.lowE[kc], sc[cnt], tot);
+            const double thr = spl_db(t);                                    // psychoac.py:173
+            if (thresh && k < M) thresh[(int64_t)blockIdx.x * M + k] = thr;
+            const double xs = ldexp(X[kc], scale);                           // codecThem.py:323 (exact)
+            const double spl = spl_db(2. * (xs * xs) / (1. / 2.)) - 6. * scale;      // psychoac.py:212
+            const double ex = spl - thr;                 // lanes past the end repeat the last line: max unchanged
+            const int bnd = S.bandOfLine[kc];
+            if (__all(bnd == __builtin_amdgcn_readfirstlane(bnd))) {
+                const double best = wave_max(ex);        // whole chunk inside one band (the wide top bands)
+                if (lane == 0) atomicMax(&bandKey[bnd], order_key(best));
+            } else {
+                atomicMax(&bandKey[bnd], order_key(ex));
             }
         }
     }
     __syncthreads();
-    // psychoac.py:216-217: SMR of a band = max over its lines
-    for (int bnd = tid; bnd < S.nBands; bnd += kThreads) {
-        const int lo = S.bandLo[bnd], n = S.bandN[bnd];
-        double best = excess[lo];
-        for (int k = 1; k < n; ++k) best = fmax(best, excess[lo + k]);
-        smr[(int64_t)blockIdx.x * S.nBands + bnd] = best;
-    }
+    for (int bnd = tid; bnd < S.nBands; bnd += kThreads)
+        smr[(int64_t)blockIdx.x * S.nBands + bnd] = order_value(bandKey[bnd]);
 }
 
 }  // namespace
