@@ -41,7 +41,7 @@ struct mrc_handle {
     std::map<std::pair<int, int>, HostShape> shapes;
     std::string error;
     // workspace of mrc_dev_encode
-    DevBuf wsLines, wsScale, wsSmr;
+    DevBuf wsLines, wsScale, wsSmr, wsPeak;
     // staging of the host entry points
     DevBuf inL, inR, inAux, inAux2, inAux3, outA, outB, outC, outD, outE, outF, outG;
     bool timing = false;
@@ -150,7 +150,7 @@ void mrc_destroy(mrc_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& kv : h->shapes) free_shape(&kv.second);
-    for (DevBuf* b : {&h->wsLines, &h->wsScale, &h->wsSmr, &h->inL, &h->inR, &h->inAux, &h->inAux2, &h->inAux3,
+    for (DevBuf* b : {&h->wsLines, &h->wsScale, &h->wsSmr, &h->wsPeak, &h->inL, &h->inR, &h->inAux, &h->inAux2, &h->inAux3,
                       &h->outA, &h->outB, &h->outC, &h->outD, &h->outE, &h->outF, &h->outG})
         b->release();
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
@@ -238,8 +238,11 @@ int mrc_dev_alloc_quant(mrc_handle* h, int a, int b, int64_t n_frames, int joint
     const HostShape* hs;
     int rc = get_shape(h, a, b, &hs);
     if (rc) return rc;
+    MRC_HIP(h, hipSetDevice(h->device));
+    MRC_HIP(h, h->wsPeak.reserve(alloc_workspace_bytes(hs->dev, n_frames, joint)));
     MRC_HIP(h, launch_alloc_quant(hs->dev, n_frames, joint, lines, overall_scale, smr, reservoir_in, ms_switch,
-                                  bit_alloc, scale_factor, mantissa, reservoir_out, pick_stream(h, stream)));
+                                  bit_alloc, scale_factor, mantissa, reservoir_out, h->wsPeak.as<double>(),
+                                  pick_stream(h, stream)));
     return MRC_OK;
 }
 
@@ -264,6 +267,7 @@ int mrc_dev_encode(mrc_handle* h, int a, int b, int64_t n_frames, const double* 
         lines = h->wsLines.as<double>();
     }
     MRC_HIP(h, h->wsSmr.reserve((size_t)n_frames * nsig * S.nBands * sizeof(double)));
+    MRC_HIP(h, h->wsPeak.reserve(alloc_workspace_bytes(S, n_frames, joint)));
     double* smr = h->wsSmr.as<double>();
     if (h->timing) MRC_HIP(h, hipEventRecord(h->ev[0], st));
     MRC_HIP(h, launch_mdct(S, n_frames, ch_left, ch_right, frame_stride, offsets, true, lines, overall_scale, st));
@@ -271,7 +275,7 @@ int mrc_dev_encode(mrc_handle* h, int a, int b, int64_t n_frames, const double* 
     MRC_HIP(h, launch_smr(S, n_frames, ch_left, ch_right, frame_stride, offsets, lines, overall_scale, smr, nullptr, h->exactSpread, st));
     if (h->timing) MRC_HIP(h, hipEventRecord(h->ev[2], st));
     MRC_HIP(h, launch_alloc_quant(S, n_frames, joint, lines, overall_scale, smr, reservoir_in, ms_switch, bit_alloc,
-                                  scale_factor, mantissa, reservoir_out, st));
+                                  scale_factor, mantissa, reservoir_out, h->wsPeak.as<double>(), st));
     if (h->timing) {
         MRC_HIP(h, hipEventRecord(h->ev[3], st));
         MRC_HIP(h, hipEventSynchronize(h->ev[3]));

@@ -137,5 +137,39 @@ __device__ double2* fft_lds(double2* A, double2* B, int n, const int* rad, int n
     return A;
 }
 
+// NumPy's pairwise summation of a contiguous run (np.sum over a 1-D slice), restated so that the
+// M/S decision sums round exactly like ms_stereo.py:19-20.  T(i) yields element i.
+template <class F> __device__ double pairwise_sum(F elem, int lo, int n) {
+    if (n < 8) {
+        double r = 0.;
+        for (int i = 0; i < n; ++i) r += elem(lo + i);
+        return r;
+    }
+    if (n <= 128) {
+        double r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = elem(lo + j);
+        int i = 8;
+        for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] += elem(lo + i + j);
+        }
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += elem(lo + i);
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return pairwise_sum(elem, lo, n2) + pairwise_sum(elem, lo + n2, n - n2);
+}
+
+// ms_stereo.py:5-27 for one band
+__device__ __forceinline__ int ms_switch_band(const double* __restrict__ L, const double* __restrict__ R, int lo,
+                                              int n) {
+    double d = pairwise_sum([&](int k) { double l = L[k], r = R[k]; return fabs(l * l - r * r); }, lo, n);
+    double s = pairwise_sum([&](int k) { double l = L[k], r = R[k]; return fabs(l * l + r * r); }, lo, n);
+    return d < 0.8 * s ? 1 : 0;
+}
+
 }  // namespace dev
 }  // namespace mrc

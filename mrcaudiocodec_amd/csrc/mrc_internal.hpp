@@ -71,7 +71,9 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const double* chL, con
                       double* smr, double* thresh, bool exactSpread, hipStream_t st);
 hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, const double* lines,
                               const int* oscale, const double* smr, const int* resIn, int* msSwitch,
-                              int* bitAlloc, int* scaleFactor, int* mantissa, int* resOut, hipStream_t st);
+                              int* bitAlloc, int* scaleFactor, int* mantissa, int* resOut, double* bandPeakWs,
+                              hipStream_t st);
+size_t alloc_workspace_bytes(const DevShape& S, int64_t nFrames, int joint);   // bandPeakWs size
 hipError_t launch_bitalloc_cases(int64_t nCases, int nBands, int maxMantBits, const int* nLines,
                                  const double* budget, const double* smr, int* bits, int* left, hipStream_t st);
 hipError_t launch_scale_factor(int64_t n, int nScaleBits, const double* v, const int* nMantBits, int* out,

@@ -1,8 +1,7 @@
 // gfx950 kernels of the encode hot path, generic in the block shape (a,b):
 //   mdct_kernel        window.py:104-121 + mdct.py:63-76 + codecThem.py:321-322
 //   (smr_kernel lives in mrc_kernels_smr.hip)
-//   alloc_quant_kernel ms_stereo.py:5-27,70-81 + bitalloc.py:106-155 + quantize.py:114-146,294-322
-//                      + codecThem.py:329-350 / 485-559
+//   (bit allocation / quantisation kernels live in mrc_kernels_alloc.hip)
 // All arithmetic is binary64.  The file is compiled with -ffp-contract=off: wherever the reference's
 // operation order decides an integer result (quantiser, bit allocation, SMR) the same separate
 // multiplies/adds are issued; fma() is used only where written explicitly.
@@ -78,175 +77,8 @@ __global__ __launch_bounds__(kThreads) void mdct_kernel(DevShape S, int nsig, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// bit allocation (bitalloc.py:106-155) on one wavefront: lane i owns band i
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bitalloc_wave(double smr, int nLines, bool active, double budget, int maxMantBits,
-                                              int nTot, int lane, int* bitsOut, double* leftOut) {
-    double run = active ? smr : -INFINITY;
-    int bits = 0;
-    double left = budget;
-    int retired = 0;
-    // every iteration either grants (<= maxMantBits-1 times per band) or retires (<= nTot times):
-    // the loop ends by itself; the counter is a guard so that no wave can spin on bad input (NaN).
-    int guard = (maxMantBits + 2) * nTot + 8;
-    while (left > 0 && guard-- > 0) {
-        double v = run;
-        int idx = lane;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            double ov = __shfl_xor(v, off);
-            int oi = __shfl_xor(idx, off);
-            if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }     // np.argmax: first maximum
-        }
-        const int wb = __shfl(bits, idx);
-        const int wn = __shfl(nLines, idx);
-        if (wb < maxMantBits && (double)wn <= left) {
-            if (wb == 0) {
-                if (lane == idx) { bits += 2; run -= 12.0; }
-                left -= (double)(2 * wn);
-            } else {
-                if (lane == idx) { bits += 1; run -= 6.0; }
-                left -= (double)wn;
-            }
-        } else {
-            if (lane == idx) run = -99999999999999999.0;
-            if (++retired == nTot) break;
-        }
-    }
-    *bitsOut = bits;
-    *leftOut = left;
-}
-
-// NumPy's pairwise summation of a contiguous run (np.sum over a 1-D slice), restated so that the
-// M/S decision sums round exactly like ms_stereo.py:19-20.  T(i) yields element i.
-template <class F> __device__ double pairwise_sum(F elem, int lo, int n) {
-    if (n < 8) {
-        double r = 0.;
-        for (int i = 0; i < n; ++i) r += elem(lo + i);
-        return r;
-    }
-    if (n <= 128) {
-        double r[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) r[j] = elem(lo + j);
-        int i = 8;
-        for (; i < n - (n % 8); i += 8) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] += elem(lo + i + j);
-        }
-        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < n; ++i) res += elem(lo + i);
-        return res;
-    }
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    return pairwise_sum(elem, lo, n2) + pairwise_sum(elem, lo + n2, n - n2);
-}
-
-// ms_stereo.py:5-27 for one band
-__device__ __forceinline__ int ms_switch_band(const double* __restrict__ L, const double* __restrict__ R, int lo,
-                                              int n) {
-    double d = pairwise_sum([&](int k) { double l = L[k], r = R[k]; return fabs(l * l - r * r); }, lo, n);
-    double s = pairwise_sum([&](int k) { double l = L[k], r = R[k]; return fabs(l * l + r * r); }, lo, n);
-    return d < 0.8 * s ? 1 : 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// M/S decision + SMR select + bit allocation + scale factors + mantissas: one wavefront per frame
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kWave) void alloc_quant_kernel(DevShape S, int joint, const double* __restrict__ lines,
-                                                            const int* __restrict__ oscale,
-                                                            const double* __restrict__ smr,
-                                                            const int* __restrict__ resIn, int* __restrict__ msSwitch,
-                                                            int* __restrict__ bitAlloc, int* __restrict__ scaleFactor,
-                                                            int* __restrict__ mantissa, int* __restrict__ resOut) {
-    __shared__ int sSw[kMaxBands];
-    __shared__ int sBa[2 * kMaxBands];
-    __shared__ int sSf[2 * kMaxBands];
-    const int lane = threadIdx.x;
-    const int64_t f = blockIdx.x;
-    const int M = S.halfN, nb = S.nBands;
-    const int nsig = joint ? 4 : 1, nstream = joint ? 2 : 1;
-    const double* X = lines + f * nsig * M;
-    const int* osc = oscale + f * nsig;
-
-    if (joint) {
-        if (lane < nb) {                                 // on the UNSCALED L/R lines (codecThem.py:436)
-            int sw = ms_switch_band(X, X + M, S.bandLo[lane], S.bandN[lane]);
-            sSw[lane] = sw;
-            msSwitch[f * nb + lane] = sw;
-        }
-    } else if (lane < nb) {
-        sSw[lane] = 0;
-    }
-    __syncthreads();
-
-    const int nTot = nstream * nb;
-    const bool active = lane < nTot;
-    const int band = active ? lane % nb : 0;
-    const int strm = active ? lane / nb : 0;
-    // stream 0 = Mid-or-Left, stream 1 = Side-or-Right (ms_stereo.py:70-81, codecThem.py:524-551)
-    const int sig = joint ? (sSw[band] ? 2 + strm : strm) : 0;
-    const double mySmr = active ? smr[(f * nsig + sig) * nb + band] : 0.0;
-    const int myLines = active ? S.bandN[band] : 0;
-    const double r = resIn ? (double)resIn[f] : 0.0;
-    double budget;
-    if (joint) { budget = S.budgetJointPre + r; budget -= S.blkswA; budget -= S.blkswB; }   // codecThem.py:390-396
-    else budget = S.budgetMono + r;                                                           // codecThem.py:308
-    int bits;
-    double left;
-    bitalloc_wave(mySmr, myLines, active, budget, S.maxMantBits, nTot, lane, &bits, &left);
-    if (lane == 0) resOut[f] = (int)left;               // int(bitsLeft): truncation toward zero (bitalloc.py:155)
-
-    if (active) {
-        // codecThem.py:346-347: scale factor from the band's largest |scaled line| with nMantBits = bitAlloc
-        const double* Xs = X + sig * M;
-        const int lo = S.bandLo[band];
-        double peak = 0.0;
-        for (int k = 0; k < myLines; ++k) peak = fmax(peak, fabs(Xs[lo + k]));
-        peak = ldexp(peak, osc[sig]);
-        int sf = scale_factor_dev(peak, S.nScaleBits, bits);
-        sBa[lane] = bits;
-        sSf[lane] = sf;
-        bitAlloc[f * nTot + lane] = bits;
-        scaleFactor[f * nTot + lane] = sf;
-    }
-    __syncthreads();
-    for (int s = 0; s < nstream; ++s) {
-        int* out = mantissa + (f * nstream + s) * M;
-        for (int k = lane; k < M; k += kWave) {
-            const int bnd = S.bandOfLine[k];
-            const int ba = sBa[s * nb + bnd];
-            int m = 0;
-            if (ba) {
-                const int sg = joint ? (sSw[bnd] ? 2 + s : s) : 0;
-                double x = ldexp(X[sg * M + k], osc[sg]);
-                m = mantissa_dev(x, sSf[s * nb + bnd], S.nScaleBits, ba);    // codecThem.py:348-349
-            }
-            out[k] = m;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // stage-level kernels for the parity tests against the reference's own modules
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kWave) void bitalloc_cases_kernel(int nBands, int maxMantBits,
-                                                               const int* __restrict__ nLines,
-                                                               const double* __restrict__ budget,
-                                                               const double* __restrict__ smr, int* __restrict__ bits,
-                                                               int* __restrict__ left) {
-    const int lane = threadIdx.x;
-    const int64_t c = blockIdx.x;
-    const bool active = lane < nBands;
-    int b;
-    double l;
-    bitalloc_wave(active ? smr[c * nBands + lane] : 0.0, active ? nLines[lane] : 0, active, budget[c], maxMantBits,
-                  nBands, lane, &b, &l);
-    if (active) bits[c * nBands + lane] = b;
-    if (lane == 0) left[c] = (int)l;
-}
-
 __global__ void scale_factor_kernel(int64_t n, int nScaleBits, const double* __restrict__ v,
                                     const int* __restrict__ nMantBits, int* __restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -311,23 +143,6 @@ hipError_t launch_unscale(int64_t nBlocks, int halfN, const double* scaled, cons
     if (total <= 0) return hipSuccess;
     hipLaunchKernelGGL(unscale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, halfN, total, scaled,
                        oscale, lines);
-    return hipGetLastError();
-}
-
-hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, const double* lines, const int* oscale,
-                              const double* smr, const int* resIn, int* msSwitch, int* bitAlloc, int* scaleFactor,
-                              int* mantissa, int* resOut, hipStream_t st) {
-    if (nFrames <= 0) return hipSuccess;
-    hipLaunchKernelGGL(alloc_quant_kernel, dim3((unsigned)nFrames), dim3(kWave), 0, st, S, joint, lines, oscale, smr,
-                       resIn, msSwitch, bitAlloc, scaleFactor, mantissa, resOut);
-    return hipGetLastError();
-}
-
-hipError_t launch_bitalloc_cases(int64_t nCases, int nBands, int maxMantBits, const int* nLines, const double* budget,
-                                 const double* smr, int* bits, int* left, hipStream_t st) {
-    if (nCases <= 0) return hipSuccess;
-    hipLaunchKernelGGL(bitalloc_cases_kernel, dim3((unsigned)nCases), dim3(kWave), 0, st, nBands, maxMantBits, nLines,
-                       budget, smr, bits, left);
     return hipGetLastError();
 }
 

@@ -1,0 +1,224 @@
+// Back end of the encode path on gfx950, after the lines and SMRs exist:
+//   band_stats_kernel   ms_stereo.py:5-27 (per-band M/S decision, joint only) and the per-band max |X| that the
+//                       scale factors need (codecThem.py:346) -- one wavefront per frame
+//   bitalloc_kernel     ms_stereo.py:70-81 (SMR select) + budgets (codecThem.py:299-308, 381-396) +
+//                       bitalloc.py:106-155 -- ONE LANE PER FRAME: the greedy loop is serial per frame, so 64
+//                       frames share a wavefront and each lane scans its own <= 64 running SMRs in LDS
+//   quantize_kernel     quantize.py:114-146 (per-band scale factor with nMantBits = allocation) and
+//                       quantize.py:294-322 (mantissas), codecThem.py:335-350 / 510-559 -- one wavefront per
+//                       (frame, stream), 16 lines per lane, coalesced int32 stores
+// Integer-deciding float64 arithmetic keeps the reference's operation order (file built with
+// -ffp-contract=off).
+#include "mrc_device.hpp"
+
+namespace mrc {
+using namespace dev;
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// band statistics: one wavefront per frame
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave) void band_stats_kernel(DevShape S, int joint, const double* __restrict__ lines,
+                                                           int* __restrict__ msSwitch, double* __restrict__ bandPeak) {
+    __shared__ unsigned long long peakBits[4 * kMaxBands];
+    const int lane = threadIdx.x;
+    const int64_t f = blockIdx.x;
+    const int M = S.halfN, nb = S.nBands;
+    const int nsig = joint ? 4 : 1;
+    const double* X = lines + f * nsig * M;
+    for (int i = lane; i < nsig * nb; i += kWave) peakBits[i] = 0ull;
+    __syncthreads();
+    // max |X| per band: |x| >= 0, so the raw bit pattern orders like the value
+    for (int s = 0; s < nsig; ++s)
+        for (int k = lane; k < M; k += kWave)
+            atomicMax(&peakBits[s * nb + S.bandOfLine[k]],
+                      (unsigned long long)__double_as_longlong(fabs(X[s * M + k])));
+    if (joint && lane < nb)                              // on the UNSCALED L/R lines (codecThem.py:436)
+        msSwitch[f * nb + lane] = ms_switch_band(X, X + M, S.bandLo[lane], S.bandN[lane]);
+    __syncthreads();
+    for (int i = lane; i < nsig * nb; i += kWave)
+        bandPeak[f * nsig * nb + i] = __longlong_as_double((long long)peakBits[i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// bit allocation (bitalloc.py:106-155), one lane per problem.  run[] / bits[] are this wave's LDS
+// slabs laid out [band][lane]: a lane's scan over bands is conflict-free and so is its indexed update.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double bitalloc_lane(double* __restrict__ run, unsigned char* __restrict__ bits,
+                                                const int* __restrict__ nLines, int nTot, int maxMantBits,
+                                                double budget, int lane, bool active) {
+    double left = budget;
+    int retired = 0;
+    // every iteration grants (<= maxMantBits-1 times per band) or retires (<= nTot times): the loop ends by
+    // itself; the counter only guards against spinning on NaN input
+    int guard = (maxMantBits + 2) * nTot + 8;
+    bool live = active && left > 0;
+    while (__any(live)) {
+        if (live) {
+            double best = run[lane];
+            int idx = 0;
+            for (int b = 1; b < nTot; ++b) {
+                const double v = run[b * kWave + lane];
+                if (v > best) { best = v; idx = b; }            // np.argmax: first maximum wins
+            }
+            const int have = bits[idx * kWave + lane];
+            const int n = nLines[idx];
+            if (have < maxMantBits && (double)n <= left) {
+                if (have == 0) {
+                    bits[idx * kWave + lane] = 2;
+                    left -= (double)(2 * n);
+                    run[idx * kWave + lane] = best - 12.0;
+                } else {
+                    bits[idx * kWave + lane] = (unsigned char)(have + 1);
+                    left -= (double)n;
+                    run[idx * kWave + lane] = best - 6.0;
+                }
+            } else {
+                run[idx * kWave + lane] = -99999999999999999.0;
+                if (++retired == nTot) live = false;
+            }
+            if (!(left > 0) || --guard <= 0) live = false;
+        }
+    }
+    return left;
+}
+
+__global__ __launch_bounds__(kWave) void bitalloc_kernel(DevShape S, int joint, int64_t nFrames,
+                                                         const double* __restrict__ smr,
+                                                         const int* __restrict__ msSwitch,
+                                                         const int* __restrict__ resIn, int* __restrict__ bitAlloc,
+                                                         int* __restrict__ resOut) {
+    extern __shared__ double lds[];                     // run[nTot][64] doubles, then bits[nTot][64] bytes, nLines[nTot]
+    const int lane = threadIdx.x;
+    const int nb = S.nBands, nsig = joint ? 4 : 1, nstream = joint ? 2 : 1;
+    const int nTot = nstream * nb;
+    double* run = lds;
+    unsigned char* bits = reinterpret_cast<unsigned char*>(lds + nTot * kWave);
+    int* nl = reinterpret_cast<int*>(bits + nTot * kWave);
+    const int64_t f0 = (int64_t)blockIdx.x * kWave;
+    const int64_t f = f0 + lane;
+    const bool active = f < nFrames;
+    for (int i = lane; i < nTot; i += kWave) nl[i] = S.bandN[i % nb];
+    // stream 0 = Mid-or-Left, stream 1 = Side-or-Right (ms_stereo.py:70-81, codecThem.py:485,524-551)
+    for (int i = 0; i < nTot; ++i) {
+        const int band = i % nb, strm = i / nb;
+        double v = 0.0;
+        if (active) {
+            const int sig = joint ? (msSwitch[f * nb + band] ? 2 + strm : strm) : 0;
+            v = smr[(f * nsig + sig) * nb + band];
+        }
+        run[i * kWave + lane] = v;
+        bits[i * kWave + lane] = 0;
+    }
+    __syncthreads();
+    const double r = (active && resIn) ? (double)resIn[f] : 0.0;
+    double budget;
+    if (joint) { budget = S.budgetJointPre + r; budget -= S.blkswA; budget -= S.blkswB; }   // codecThem.py:390-396
+    else budget = S.budgetMono + r;                                                           // codecThem.py:308
+    const double left = bitalloc_lane(run, bits, nl, nTot, S.maxMantBits, budget, lane, active);
+    if (active) {
+        resOut[f] = (int)left;                            // int(bitsLeft): truncation toward zero (bitalloc.py:155)
+        for (int i = 0; i < nTot; ++i) bitAlloc[f * nTot + i] = bits[i * kWave + lane];
+    }
+}
+
+// stage-level entry (mrc_bitalloc): independent problems with explicit budgets, shared nLines
+__global__ __launch_bounds__(kWave) void bitalloc_cases_kernel(int64_t nCases, int nBands, int maxMantBits,
+                                                               const int* __restrict__ nLines,
+                                                               const double* __restrict__ budget,
+                                                               const double* __restrict__ smr, int* __restrict__ bitsOut,
+                                                               int* __restrict__ left) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    double* run = lds;
+    unsigned char* bits = reinterpret_cast<unsigned char*>(lds + nBands * kWave);
+    int* nl = reinterpret_cast<int*>(bits + nBands * kWave);
+    const int64_t c = (int64_t)blockIdx.x * kWave + lane;
+    const bool active = c < nCases;
+    for (int i = lane; i < nBands; i += kWave) nl[i] = nLines[i];
+    for (int i = 0; i < nBands; ++i) {
+        run[i * kWave + lane] = active ? smr[c * nBands + i] : 0.0;
+        bits[i * kWave + lane] = 0;
+    }
+    __syncthreads();
+    const double l = bitalloc_lane(run, bits, nl, nBands, maxMantBits, active ? budget[c] : 0.0, lane, active);
+    if (active) {
+        left[c] = (int)l;
+        for (int i = 0; i < nBands; ++i) bitsOut[c * nBands + i] = bits[i * kWave + lane];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scale factors + mantissas: one wavefront per (frame, stream)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave) void quantize_kernel(DevShape S, int joint, const double* __restrict__ lines,
+                                                         const int* __restrict__ oscale,
+                                                         const double* __restrict__ bandPeak,
+                                                         const int* __restrict__ msSwitch,
+                                                         const int* __restrict__ bitAlloc,
+                                                         int* __restrict__ scaleFactor, int* __restrict__ mantissa) {
+    __shared__ int sBa[kMaxBands], sSf[kMaxBands], sSig[kMaxBands];
+    const int lane = threadIdx.x;
+    const int nstream = joint ? 2 : 1, nsig = joint ? 4 : 1;
+    const int64_t f = blockIdx.x / nstream;
+    const int strm = blockIdx.x % nstream;
+    const int M = S.halfN, nb = S.nBands;
+    const double* X = lines + f * nsig * M;
+    const int* osc = oscale + f * nsig;
+    if (lane < nb) {
+        const int sig = joint ? (msSwitch[f * nb + lane] ? 2 + strm : strm) : 0;
+        const int ba = bitAlloc[(f * nstream + strm) * nb + lane];
+        // codecThem.py:346-347: ScaleFactor(max |scaled line| of the band, nScaleBits, nMantBits = bitAlloc);
+        // scaling by 2^overallScale is exact, so max and scale commute
+        const double peak = ldexp(bandPeak[(f * nsig + sig) * nb + lane], osc[sig]);
+        const int sf = scale_factor_dev(peak, S.nScaleBits, ba);
+        sBa[lane] = ba;
+        sSf[lane] = sf;
+        sSig[lane] = sig;
+        scaleFactor[(f * nstream + strm) * nb + lane] = sf;
+    }
+    __syncthreads();
+    int* out = mantissa + (f * nstream + strm) * M;
+    for (int k = lane; k < M; k += kWave) {
+        const int bnd = S.bandOfLine[k];
+        const int ba = sBa[bnd];
+        int m = 0;
+        if (ba) {
+            const int sg = sSig[bnd];
+            m = mantissa_dev(ldexp(X[sg * M + k], osc[sg]), sSf[bnd], S.nScaleBits, ba);   // codecThem.py:348-349
+        }
+        out[k] = m;
+    }
+}
+
+}  // namespace
+
+size_t alloc_workspace_bytes(const DevShape& S, int64_t nFrames, int joint) {
+    return (size_t)nFrames * (joint ? 4 : 1) * S.nBands * sizeof(double);
+}
+
+hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, const double* lines, const int* oscale,
+                              const double* smr, const int* resIn, int* msSwitch, int* bitAlloc, int* scaleFactor,
+                              int* mantissa, int* resOut, double* bandPeakWs, hipStream_t st) {
+    if (nFrames <= 0) return hipSuccess;
+    const int nTot = (joint ? 2 : 1) * S.nBands;
+    hipLaunchKernelGGL(band_stats_kernel, dim3((unsigned)nFrames), dim3(kWave), 0, st, S, joint, lines, msSwitch,
+                       bandPeakWs);
+    const size_t lds = (size_t)nTot * kWave * (sizeof(double) + 1) + (size_t)nTot * sizeof(int);
+    hipLaunchKernelGGL(bitalloc_kernel, dim3((unsigned)((nFrames + kWave - 1) / kWave)), dim3(kWave), lds, st, S, joint,
+                       nFrames, smr, msSwitch, resIn, bitAlloc, resOut);
+    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)(nFrames * (joint ? 2 : 1))), dim3(kWave), 0, st, S, joint, lines,
+                       oscale, bandPeakWs, msSwitch, bitAlloc, scaleFactor, mantissa);
+    return hipGetLastError();
+}
+
+hipError_t launch_bitalloc_cases(int64_t nCases, int nBands, int maxMantBits, const int* nLines, const double* budget,
+                                 const double* smr, int* bits, int* left, hipStream_t st) {
+    if (nCases <= 0) return hipSuccess;
+    const size_t lds = (size_t)nBands * kWave * (sizeof(double) + 1) + (size_t)nBands * sizeof(int);
+    hipLaunchKernelGGL(bitalloc_cases_kernel, dim3((unsigned)((nCases + kWave - 1) / kWave)), dim3(kWave), lds, st,
+                       nCases, nBands, maxMantBits, nLines, budget, smr, bits, left);
+    return hipGetLastError();
+}
+
+}  // namespace mrc

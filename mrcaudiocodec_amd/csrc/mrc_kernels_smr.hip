@@ -60,9 +60,16 @@ __device__ __forceinline__ double exp2_poly(double f) {
 }
 
 // 2^t for finite t; t == 0 gives exactly 1 (a line inside +-1/2 Bark gets exactly the masker's intensity)
+// Requires |t| < 900 (here -230 < t <= 0): the integer part is taken from the low mantissa bits of
+// t + 1.5*2^52 and applied by adding it to the exponent field of the polynomial value (in [0.70, 1.42]),
+// which cannot leave the normal range for such t.
 __device__ __forceinline__ double exp2_fast(double t) {
-    const double k = rint(t);
-    return ldexp(exp2_poly(t - k), (int)k);
+    const double shifter = 0x1.8p52;
+    const double tt = t + shifter;                       // low 32 mantissa bits = rint(t), two's complement
+    const double k = tt - shifter;
+    const double p = exp2_poly(t - k);
+    const int hi = __double2hiint(p) + (__double2loint(tt) << 20);
+    return __hiloint2double(hi, __double2loint(p));
 }
 
 // 2^(hi + lo), |lo| << 1
@@ -292,17 +299,18 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
             mLow = mEnd = mExp = 0;
 #endif
             const int mPlain = min(mExp, mLow);
+            const double zq = z - 0.5;                 // u = max(z - z_m - 1/2, 0), one subtraction per pair
             // some line of the chunk is above the masker's band, every line sees the masker
 #pragma unroll 4
             for (int m = 0; m < mPlain; ++m) {
                 const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
-                const double u = fmax((z - zm) - 0.5, 0.0);
+                const double u = fmax(zq - zm, 0.0);
                 tot = fma(I, exp2_fast(sl * u), tot);
             }
             // same, but part of the chunk lies below the masker's band (only when the chunk spans > 1 Bark)
             for (int m = mPlain; m < mExp; ++m) {
                 const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
-                const double u = fmax((z - zm) - 0.5, 0.0);
+                const double u = fmax(zq - zm, 0.0);
                 tot = fma(m < cnt ? I : 0.0, exp2_fast(sl * u), tot);
             }
             // no line of the chunk is above the band: every line that sees the masker is inside +-1/2 Bark
