@@ -87,6 +87,7 @@ def main():
     import torch
     import torch.distributed as dist
     from mrcaudiocodec_amd.batch import StreamEncoder
+    from mrcaudiocodec_amd.shard import shard_frames, max_over_ranks
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -101,6 +102,10 @@ def main():
 
     enc = StreamEncoder(device_id=local)
     F = args.frames
+    # weak scaling: the job is a world*F-frame batch cut into contiguous per-rank ranges (shard.py); the
+    # content is synthetic, so each rank generates its own range (one-hop halo included) instead of receiving it
+    first, count = shard_frames(world * F, world, rank)
+    assert count == F
     pcm = make_noise_stream(torch, device, F, seed=1234 + rank)
 
     def barrier():
@@ -118,10 +123,7 @@ def main():
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     barrier()
-    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, device)
 
     # per-kernel device time, hipEvents on the launch stream (outside the timed region)
     enc.h.set_timing(True)
@@ -136,7 +138,7 @@ def main():
 
     if rank == 0:
         total_samples = float(F) * HOP * world * args.steps
-        names = ["mdct_kernel", "smr_kernel", "alloc_quant_kernel"]
+        names = ["mdct_long_kernel", "smr_kernel", "band_stats+bitalloc+quantize kernels"]
         per_unit = [BYTES_MDCT, BYTES_SMR, BYTES_ALLOC]
         kernels = []
         for nm, ms, bpu in zip(names, stage_ms, per_unit):

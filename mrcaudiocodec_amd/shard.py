@@ -1,0 +1,34 @@
+"""
+Frame sharding for multi-GPU runs: frames are independent given `reservoir_in`, so a batch
+is cut into contiguous frame ranges, one per rank, and each rank reads its own slice of the hop-overlapped
+stream plus a one-hop halo (the `priorBlock` of its first frame, pacfileThem.py:628-631).  No collective
+touches the data path; torch.distributed is only used for the barrier and the max-over-ranks of a timing.
+"""
+
+
+def shard_frames(n_frames, world, rank):
+    """Contiguous, balanced ranges: returns (first_frame, n_local).  The first `n_frames % world` ranks get one more."""
+    if world < 1 or not (0 <= rank < world) or n_frames < 0:
+        raise ValueError("bad shard request")
+    base, extra = divmod(n_frames, world)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def shard_samples(first_frame, n_local, hop):
+    """Sample range [start, stop) of the stream that frames first_frame .. first_frame+n_local-1 read:
+    frame f covers [f*hop, f*hop + 2*hop), so the slice carries one hop of halo in front of its new hops."""
+    if n_local == 0:
+        return first_frame * hop, first_frame * hop
+    return first_frame * hop, (first_frame + n_local + 1) * hop
+
+
+def max_over_ranks(value, device=None):
+    """Max of a Python float over all ranks (identity when torch.distributed is not initialised)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

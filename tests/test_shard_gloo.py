@@ -1,0 +1,75 @@
+"""
+The N > 1 path on CPU: world_size-2 gloo processes shard one stream by contiguous frame ranges with a
+one-hop halo (mrcaudiocodec_amd.shard), encode their shard independently and the concatenation equals the
+unsharded result -- no collective on the data path.  There is no GPU here, so the per-shard worker is the
+oracle (the checker); what is under test is the sharding arithmetic and the rank plumbing bench.py uses.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from mrcaudiocodec_amd import shard
+
+
+def test_shard_ranges_cover_exactly():
+    for n in (0, 1, 7, 64, 1000):
+        for world in (1, 2, 3, 8):
+            got = [shard.shard_frames(n, world, r) for r in range(world)]
+            assert got[0][0] == 0 and sum(c for _, c in got) == n
+            for (f0, c0), (f1, _) in zip(got, got[1:]):
+                assert f0 + c0 == f1
+            assert max(c for _, c in got) - min(c for _, c in got) <= 1
+    assert shard.shard_samples(5, 3, 1024) == (5 * 1024, 9 * 1024)
+    with pytest.raises(ValueError):
+        shard.shard_frames(4, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_frames, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mrcaudiocodec_amd import synth
+    from oracle import fast
+    s = synth.c3_stereo(n_frames)                              # every rank can regenerate the synthetic stream
+    first, count = shard.shard_frames(n_frames, world, rank)
+    a, b = shard.shard_samples(first, count, 1024)
+    local = s[:, a:b]                                          # this rank's slice, halo included
+    bl = np.array(fast.blocks_from_stream(local[0], 1024))
+    br = np.array(fast.blocks_from_stream(local[1], 1024))
+    assert bl.shape[0] == count
+    r = fast.encode_joint_batch(bl, br, 1024, 1024)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), first=first, mantissa=r["mantissa"], bit_alloc=r["bit_alloc"],
+             ms_switch=r["ms_switch"], reservoir_out=r["reservoir_out"])
+    dist.barrier()
+    t = shard.max_over_ranks(1.0 + rank)                       # the reduction bench.py uses for its clock
+    assert t == float(world)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_encode_equals_unsharded(tmp_path):
+    torch = pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    from mrcaudiocodec_amd import synth
+    from oracle import fast
+    n_frames, world = 7, 2
+    mp.spawn(_worker, args=(world, _free_port(), n_frames, str(tmp_path)), nprocs=world, join=True)
+    s = synth.c3_stereo(n_frames)
+    ref = fast.encode_joint_batch(np.array(fast.blocks_from_stream(s[0], 1024)),
+                                  np.array(fast.blocks_from_stream(s[1], 1024)), 1024, 1024)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    assert [int(p["first"]) for p in parts] == [0, 4]
+    for k in ("mantissa", "bit_alloc", "ms_switch", "reservoir_out"):
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), ref[k]), k
