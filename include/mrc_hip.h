@@ -145,6 +145,37 @@ int mrc_dev_encode(mrc_handle* h, int a, int b, int64_t n_frames, const double* 
                    int32_t* overall_scale, int32_t* ms_switch, int32_t* bit_alloc, int32_t* scale_factor,
                    int32_t* mantissa, int32_t* reservoir_out, double* lines_out, void* stream);
 
+/* ---- host-side back end: Huffman table choice + `.pac` bit packing (no GPU, no handle) -----------
+ * BASELINE.json's north_star keeps huffman.py / bitpack.py on the host; these are their C++ form, fed with
+ * the dense outputs of mrc_encode_mono / mrc_encode_joint.  Table ids: sorted names (percussive 0,
+ * silence 1, speech 2, tonal 3), 15 = raw mantissas (codecThem.py:149). */
+
+/* psychoac.py:86-105 + pacfileThem.py:637-645: lines per scale-factor band of block shape (a,b). */
+int mrc_band_table(const mrc_config* cfg, int a, int b, int32_t* n_bands, int32_t* n_lines /*[MRC_MAX_BANDS]*/);
+/* Upper bound of the bytes one block can pack to (all its channel chunks, length prefixes included). */
+int64_t mrc_pack_bound(const mrc_config* cfg, int a, int b, int n_channels, int joint);
+/* pacfileThem.py:586-613 (file header; num_samples is padded by the reference's inverted test). */
+int mrc_pac_header(const mrc_config* cfg, int n_channels, uint32_t num_samples, uint8_t* out, int64_t out_cap,
+                   int64_t* out_len);
+/* What PACFile.WriteDataBlock appends per block (pacfileThem.py:652-790) for n_channels independent
+ * channels: per channel `<L nBytes` + MSB-first payload {huffTable:4, blkswA, blkswB, overallScale, band
+ * records}.  Arrays: overall_scale [n][nch], scale_factor / bit_alloc [n][nch][nBands], mantissa
+ * [n][nch][N/2] dense.  use_huffman = 0 writes raw mantissas (EncodeNoHuff), else the table choice of
+ * codecThem.py:136-203 runs per channel; huff_table / bits_saved ([n][nch], may be NULL) return the chosen
+ * table id and the reservoir credit `bits_saved` (codecThem.py:202,224).  block_offset [n+1] = byte
+ * offsets of the blocks in `out`.  Returns MRC_ERR_NOMEM if out_cap is too small. */
+int mrc_pack_blocks(const mrc_config* cfg, int64_t n_blocks, int n_channels, int a, int b, int use_huffman,
+                    const int32_t* overall_scale, const int32_t* scale_factor, const int32_t* bit_alloc,
+                    const int32_t* mantissa, uint8_t* out, int64_t out_cap, int64_t* block_offset,
+                    int32_t* huff_table, int32_t* bits_saved);
+/* What PACFile.JointWriteDataBlock appends per block (pacfileThem.py:825-970): channel 0 additionally
+ * carries overallScale[L,R,M,S] and ms_switch.  overall_scale [n][4], ms_switch [n][nBands], the rest
+ * [n][2][...]. */
+int mrc_pack_joint_blocks(const mrc_config* cfg, int64_t n_blocks, int a, int b, int use_huffman,
+                          const int32_t* overall_scale, const int32_t* ms_switch, const int32_t* scale_factor,
+                          const int32_t* bit_alloc, const int32_t* mantissa, uint8_t* out, int64_t out_cap,
+                          int64_t* block_offset, int32_t* huff_table, int32_t* bits_saved);
+
 /* Per-stage device time of the most recent mrc_dev_encode / stage call when timing is enabled
  * (hipEvents on the launch stream; the call then synchronises).  ms[0..2] = mdct, smr, alloc+quant. */
 int mrc_set_timing(mrc_handle* h, int enabled);

@@ -15,6 +15,7 @@ MRC_MAX_BANDS = 32
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)
 _f64p = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
 
 
 class MrcConfig(C.Structure):
@@ -79,6 +80,13 @@ def _load():
         "mrc_dev_alloc_quant": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_int] + [C.c_void_p] * 10),
         "mrc_dev_encode": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64] +
                            [C.c_void_p] * 10),
+        "mrc_band_table": (C.c_int, [C.POINTER(MrcConfig), C.c_int, C.c_int, _i32p, _i32p]),
+        "mrc_pack_bound": (C.c_int64, [C.POINTER(MrcConfig), C.c_int, C.c_int, C.c_int, C.c_int]),
+        "mrc_pac_header": (C.c_int, [C.POINTER(MrcConfig), C.c_int, C.c_uint32, _u8p, C.c_int64, _i64p]),
+        "mrc_pack_blocks": (C.c_int, [C.POINTER(MrcConfig), C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, _i32p,
+                                      _i32p, _i32p, _i32p, _u8p, C.c_int64, _i64p, _i32p, _i32p]),
+        "mrc_pack_joint_blocks": (C.c_int, [C.POINTER(MrcConfig), C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p,
+                                            _i32p, _i32p, _i32p, _u8p, C.c_int64, _i64p, _i32p, _i32p]),
         "mrc_set_timing": (C.c_int, [H, C.c_int]),
         "mrc_set_option": (C.c_int, [H, C.c_int, C.c_int]),
         "mrc_get_stage_ms": (C.c_int, [H, _f64p]),

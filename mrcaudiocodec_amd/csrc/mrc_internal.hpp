@@ -50,6 +50,7 @@ struct HostShape {
 };
 
 // mrc_tables.cpp
+bool band_table(const mrc_config& cfg, int a, int b, std::vector<int>* count);   // host only
 bool build_shape(const mrc_config& cfg, int a, int b, HostShape* out, std::string* err);
 void free_shape(HostShape* s);
 int scale_factor_host(double v, int nScaleBits, int nMantBits);

@@ -1,0 +1,271 @@
+// Host-side back end of the encoder: Huffman table choice + recoding and `.pac` bit packing.
+// BASELINE.json's north_star keeps huffman.py / bitpack.py on the host; this is their C++ form so that the
+// GPU path is not throttled by per-bit Python (bitpack.py:36-101) and per-block pickle loads
+// (codecThem.py:151-153).  No GPU, no handle: pure functions of the dense outputs of mrc_encode_*.
+//
+//   Huffman gain / table choice   codecThem.py:136-203
+//   chunk sizes                   pacfileThem.py:652-707 (independent channels), 825-880 (joint)
+//   chunk payloads                pacfileThem.py:716-781, 892-963; bit order of bitpack.py:36-101
+//   file header                   pacfileThem.py:586-613
+// Table ids: sorted table names (percussive 0, silence 1, speech 2, tonal 3), 15 = raw; see DESIGN.md.
+#include "mrc_internal.hpp"
+
+#include <cstring>
+
+namespace {
+
+struct HuffTable {
+    int escape;
+    int nCodes;
+    struct { int value; const char* code; } codes[16];
+};
+
+// training_data/*_table.pkl of the reference, as data (tools/check_huffman_tables.py)
+const HuffTable kTables[4] = {
+    {16, 16, {{0, "0"}, {1, "1110"}, {2, "110"}, {3, "111101"}, {4, "101"}, {5, "1000"}, {6, "111100"},
+              {7, "11111100"}, {8, "10010"}, {9, "111110"}, {10, "1111111"}, {11, "1001101"}, {12, "1001100"},
+              {13, "111111011"}, {14, "111111010"}, {16, "100111"}}},
+    {11, 11, {{0, "11"}, {1, "000"}, {2, "100"}, {3, "00101"}, {4, "01"}, {5, "0011"}, {6, "101101"},
+              {8, "10111"}, {9, "00100"}, {10, "101100"}, {11, "1010"}}},
+    {7, 16, {{0, "11"}, {1, "1001"}, {2, "101"}, {3, "100011"}, {4, "00"}, {5, "0100"}, {6, "100000"},
+             {7, "0101"}, {8, "0111"}, {9, "01101"}, {10, "100001"}, {11, "1000101"}, {12, "0110000"},
+             {16, "011001"}, {17, "1000100"}, {32, "0110001"}}},
+    {7, 16, {{0, "0"}, {1, "11110"}, {2, "110"}, {3, "1111101"}, {4, "101"}, {5, "1001011"}, {6, "11111101"},
+             {7, "1000"}, {8, "1110"}, {9, "1111111"}, {10, "10010100"}, {16, "10011"}, {17, "1111100"},
+             {18, "11111100"}, {32, "100100"}, {64, "10010101"}}},
+};
+constexpr int kRawTable = 15;       // codecThem.py:149
+constexpr int kLutSize = 65;        // largest table value is 64
+
+struct Lut {
+    unsigned char len[4][kLutSize];
+    unsigned short bits[4][kLutSize];
+    Lut() {
+        std::memset(len, 0, sizeof(len));
+        std::memset(bits, 0, sizeof(bits));
+        for (int t = 0; t < 4; ++t)
+            for (int i = 0; i < kTables[t].nCodes; ++i) {
+                const char* c = kTables[t].codes[i].code;
+                unsigned v = 0;
+                int n = 0;
+                for (; c[n]; ++n) v = (v << 1) | (unsigned)(c[n] - '0');
+                len[t][kTables[t].codes[i].value] = (unsigned char)n;
+                bits[t][kTables[t].codes[i].value] = (unsigned short)v;
+            }
+    }
+};
+const Lut kLut;
+
+// MSB-first writer, same byte image as bitpack.py:36-101 (zero-initialised buffer, bits OR-ed in)
+struct BitWriter {
+    uint8_t* p;
+    uint64_t acc = 0;
+    int n = 0;
+    explicit BitWriter(uint8_t* dst) : p(dst) {}
+    void put(uint32_t info, int nBits) {              // lowest nBits of info
+        if (nBits <= 0) return;
+        uint64_t v = nBits >= 32 ? info : (info & ((1u << nBits) - 1u));
+        acc = (acc << nBits) | v;
+        n += nBits;
+        while (n >= 8) {
+            *p++ = (uint8_t)(acc >> (n - 8));
+            n -= 8;
+        }
+    }
+    void flush() {
+        if (n > 0) { *p++ = (uint8_t)(acc << (8 - n)); n = 0; }
+    }
+};
+
+struct ChannelPlan {
+    int table;          // 0..3 or 15
+    int64_t mantBits;   // bits of the mantissa part as the writer emits them
+    int bitsSaved;      // codecThem.py:202 (raw - best priced cost)
+};
+
+// codecThem.py:136-203.  The price of a table counts the escape VALUE itself as its code only
+// (lines 169-172) although the writer emits code + raw mantissa for it (194-200): kept, so the choice and
+// bits_saved equal the reference's; mantBits is what is really written (pacfileThem.py:685-703).
+ChannelPlan plan_channel(const int32_t* ba, const int32_t* mant, const std::vector<int>& nLines, int useHuffman) {
+    const int nb = (int)nLines.size();
+    int64_t raw = 0;
+    for (int b = 0; b < nb; ++b)
+        if (ba[b]) raw += (int64_t)ba[b] * nLines[b];
+    ChannelPlan plan{kRawTable, raw, 0};
+    if (!useHuffman) return plan;
+    int64_t best = raw;
+    for (int t = 0; t < 4; ++t) {
+        const int esc = kTables[t].escape;
+        const int escLen = kLut.len[t][esc];
+        int64_t priced = 0, written = 0;
+        int k = 0;
+        for (int b = 0; b < nb; ++b) {
+            const int n = nLines[b];
+            if (ba[b]) {
+                for (int i = 0; i < n; ++i) {
+                    const int32_t v = mant[k + i];
+                    const int len = (v >= 0 && v < kLutSize) ? kLut.len[t][v] : 0;
+                    if (len == 0) { priced += ba[b] + escLen; written += ba[b] + escLen; }
+                    else if (v == esc) { priced += len; written += len + ba[b]; }
+                    else { priced += len; written += len; }
+                }
+            }
+            k += n;
+        }
+        if (priced < best) { best = priced; plan.table = t; plan.mantBits = written; }
+    }
+    plan.bitsSaved = (int)(raw - best);
+    return plan;
+}
+
+void write_band_records(BitWriter& w, const mrc_config& cfg, const int32_t* sf, const int32_t* ba, const int32_t* mant,
+                        const std::vector<int>& nLines, int table) {
+    const int nb = (int)nLines.size();
+    int k = 0;
+    for (int b = 0; b < nb; ++b) {
+        w.put((uint32_t)(ba[b] ? ba[b] - 1 : 0), cfg.n_mant_size_bits);      // pacfileThem.py:730-732
+        w.put((uint32_t)sf[b], cfg.n_scale_bits);
+        const int n = nLines[b];
+        if (ba[b]) {
+            for (int i = 0; i < n; ++i) {
+                const int32_t v = mant[k + i];
+                if (table == kRawTable) { w.put((uint32_t)v, ba[b]); continue; }
+                const int esc = kTables[table].escape;
+                const int len = (v >= 0 && v < kLutSize) ? kLut.len[table][v] : 0;
+                if (len != 0 && v != esc) {
+                    w.put(kLut.bits[table][v], len);
+                } else {                                                      // codecThem.py:194-200
+                    w.put(kLut.bits[table][esc], kLut.len[table][esc]);
+                    w.put((uint32_t)v, ba[b]);
+                }
+            }
+        }
+        k += n;
+    }
+}
+
+inline void put_u32le(uint8_t* p, uint32_t v) { p[0] = v & 255; p[1] = (v >> 8) & 255; p[2] = (v >> 16) & 255; p[3] = v >> 24; }
+
+bool shape_ok(const mrc_config* cfg, int a, int b) {
+    return cfg && a > 0 && b > 0 && (a + b) % 2 == 0 && cfg->n_mdct_lines > 0 && cfg->n_scale_bits >= 1 &&
+           cfg->n_scale_bits <= 4 && cfg->n_mant_size_bits >= 1 && cfg->n_mant_size_bits <= 4;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mrc_band_table(const mrc_config* cfg, int a, int b, int32_t* n_bands, int32_t* n_lines) {
+    if (!shape_ok(cfg, a, b) || !n_bands) return MRC_ERR_INVALID;
+    std::vector<int> cnt;
+    if (!mrc::band_table(*cfg, a, b, &cnt)) return MRC_ERR_INVALID;
+    *n_bands = (int32_t)cnt.size();
+    if (n_lines) for (size_t i = 0; i < cnt.size(); ++i) n_lines[i] = cnt[i];
+    return MRC_OK;
+}
+
+int64_t mrc_pack_bound(const mrc_config* cfg, int a, int b, int n_channels, int joint) {
+    if (!shape_ok(cfg, a, b) || n_channels < 1) return MRC_ERR_INVALID;
+    std::vector<int> cnt;
+    if (!mrc::band_table(*cfg, a, b, &cnt)) return MRC_ERR_INVALID;
+    // worst case per line: 16 raw bits + the longest escape code (6 bits); header fields on top
+    const int64_t half = (a + b) / 2;
+    int64_t bits = 4 + 2 + 4 * cfg->n_scale_bits + (int64_t)cnt.size() * (1 + cfg->n_mant_size_bits + cfg->n_scale_bits) +
+                   half * (16 + 9);
+    (void)joint;
+    return (int64_t)n_channels * (4 + (bits + 7) / 8);
+}
+
+int mrc_pac_header(const mrc_config* cfg, int n_channels, uint32_t num_samples, uint8_t* out, int64_t out_cap,
+                   int64_t* out_len) {
+    if (!cfg || !out || !out_len || n_channels < 1) return MRC_ERR_INVALID;
+    std::vector<int> cnt;
+    if (!mrc::band_table(*cfg, cfg->n_mdct_lines, cfg->n_mdct_lines, &cnt)) return MRC_ERR_INVALID;
+    const int64_t need = 4 + 4 + 2 + 4 + 4 + 2 + 2 + 4 + 2 * (int64_t)cnt.size();
+    if (out_cap < need) return MRC_ERR_INVALID;
+    // pacfileThem.py:595-597: padded only when numSamples ALREADY is a multiple of nMDCTLines (inverted test)
+    if (num_samples % (uint32_t)cfg->n_mdct_lines == 0) num_samples += (uint32_t)cfg->n_mdct_lines;
+    uint8_t* p = out;
+    std::memcpy(p, "PAC ", 4); p += 4;
+    put_u32le(p, (uint32_t)cfg->sample_rate); p += 4;
+    p[0] = n_channels & 255; p[1] = (n_channels >> 8) & 255; p += 2;
+    put_u32le(p, num_samples); p += 4;
+    put_u32le(p, (uint32_t)cfg->n_mdct_lines); p += 4;
+    p[0] = cfg->n_scale_bits; p[1] = 0; p += 2;
+    p[0] = cfg->n_mant_size_bits; p[1] = 0; p += 2;
+    put_u32le(p, (uint32_t)cnt.size()); p += 4;
+    for (int c : cnt) { p[0] = c & 255; p[1] = (c >> 8) & 255; p += 2; }
+    *out_len = p - out;
+    return MRC_OK;
+}
+
+// One chunk pair/set per block, exactly the bytes WriteDataBlock / JointWriteDataBlock append.
+static int pack_blocks(const mrc_config* cfg, int64_t n, int nch, int a, int b, int joint, int use_huffman,
+                       const int32_t* overall_scale, const int32_t* ms_switch, const int32_t* scale_factor,
+                       const int32_t* bit_alloc, const int32_t* mantissa, uint8_t* out, int64_t out_cap,
+                       int64_t* block_offset, int32_t* huff_table, int32_t* bits_saved) {
+    if (!shape_ok(cfg, a, b) || n < 0 || !overall_scale || !scale_factor || !bit_alloc || !mantissa || !out ||
+        !block_offset || (joint && (!ms_switch || nch != 2)) || nch < 1)
+        return MRC_ERR_INVALID;
+    std::vector<int> nLines;
+    if (!mrc::band_table(*cfg, a, b, &nLines)) return MRC_ERR_INVALID;
+    const int nb = (int)nLines.size();
+    const int half = (a + b) / 2;
+    const int nScalePerBlock = joint ? 4 : nch;
+    const uint32_t bitA = (uint32_t)(1 - a / cfg->n_mdct_lines), bitB = (uint32_t)(1 - b / cfg->n_mdct_lines);   // py2 int division
+    int64_t pos = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        block_offset[i] = pos;
+        for (int ch = 0; ch < nch; ++ch) {
+            const int32_t* sf = scale_factor + (i * nch + ch) * nb;
+            const int32_t* ba = bit_alloc + (i * nch + ch) * nb;
+            const int32_t* dense = mantissa + (i * nch + ch) * (int64_t)half;
+            const ChannelPlan plan = plan_channel(ba, dense, nLines, use_huffman);
+            if (huff_table) huff_table[i * nch + ch] = plan.table;
+            if (bits_saved) bits_saved[i * nch + ch] = plan.bitsSaved;
+            int64_t bits = 4 + cfg->blksw_bits_a + cfg->blksw_bits_b + (int64_t)nb * (cfg->n_mant_size_bits + cfg->n_scale_bits) +
+                           plan.mantBits;
+            if (joint) { if (ch == 0) bits += nb + 4 * cfg->n_scale_bits; }       // pacfileThem.py:826-833
+            else bits += cfg->n_scale_bits;                                       // pacfileThem.py:655
+            const int64_t nBytes = (bits + 7) / 8;                                // pacfileThem.py:706-707
+            if (pos + 4 + nBytes > out_cap) return MRC_ERR_NOMEM;
+            put_u32le(out + pos, (uint32_t)nBytes);
+            BitWriter w(out + pos + 4);
+            w.put((uint32_t)plan.table, 4);
+            w.put(bitA, cfg->blksw_bits_a);
+            w.put(bitB, cfg->blksw_bits_b);
+            if (joint) {
+                if (ch == 0) {
+                    for (int s = 0; s < 4; ++s) w.put((uint32_t)overall_scale[i * 4 + s], cfg->n_scale_bits);   // L,R,M,S
+                    for (int k = 0; k < nb; ++k) w.put((uint32_t)ms_switch[i * nb + k], 1);
+                }
+            } else {
+                w.put((uint32_t)overall_scale[i * nScalePerBlock + ch], cfg->n_scale_bits);
+            }
+            write_band_records(w, *cfg, sf, ba, dense, nLines, plan.table);
+            w.flush();
+            if (w.p - (out + pos + 4) != nBytes) return MRC_ERR_INVALID;          // size law and writer disagree: bug
+            pos += 4 + nBytes;
+        }
+    }
+    block_offset[n] = pos;
+    return MRC_OK;
+}
+
+int mrc_pack_blocks(const mrc_config* cfg, int64_t n_blocks, int n_channels, int a, int b, int use_huffman,
+                    const int32_t* overall_scale, const int32_t* scale_factor, const int32_t* bit_alloc,
+                    const int32_t* mantissa, uint8_t* out, int64_t out_cap, int64_t* block_offset,
+                    int32_t* huff_table, int32_t* bits_saved) {
+    return pack_blocks(cfg, n_blocks, n_channels, a, b, 0, use_huffman, overall_scale, nullptr, scale_factor, bit_alloc,
+                       mantissa, out, out_cap, block_offset, huff_table, bits_saved);
+}
+
+int mrc_pack_joint_blocks(const mrc_config* cfg, int64_t n_blocks, int a, int b, int use_huffman,
+                          const int32_t* overall_scale, const int32_t* ms_switch, const int32_t* scale_factor,
+                          const int32_t* bit_alloc, const int32_t* mantissa, uint8_t* out, int64_t out_cap,
+                          int64_t* block_offset, int32_t* huff_table, int32_t* bits_saved) {
+    return pack_blocks(cfg, n_blocks, 2, a, b, 1, use_huffman, overall_scale, ms_switch, scale_factor, bit_alloc,
+                       mantissa, out, out_cap, block_offset, huff_table, bits_saved);
+}
+
+}  // extern "C"

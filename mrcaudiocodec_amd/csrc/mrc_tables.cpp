@@ -114,6 +114,22 @@ int scale_factor_host(double v, int nScaleBits, int nMantBits) {
     return lz < cap ? lz : cap;
 }
 
+// psychoac.py:86-105 with the limits chosen at pacfileThem.py:637-645: 25 critical bands for long+long
+// blocks, the 9-band table for every other shape.  Band i takes the not-yet-assigned lines whose centre
+// (n+1/2) fs/(2 halfN) lies below limit i; the last band takes the rest.
+bool band_table(const mrc_config& cfg, int a, int b, std::vector<int>* count) {
+    const int N = a + b, halfN = N / 2;
+    const bool isLong = (N == 2 * cfg.n_mdct_lines);
+    const int* lim = isLong ? kLongLimits : kShortLimits;
+    const int nb = isLong ? 25 : 9;
+    count->assign(nb, 0);
+    int j = 0;
+    for (int i = 0; i < nb - 1; ++i)
+        while (j < halfN && (j + 0.5) * (((double)cfg.sample_rate / halfN) / 2.) < lim[i]) { ++(*count)[i]; ++j; }
+    (*count)[nb - 1] = halfN - j;
+    return (*count)[nb - 1] >= 0;
+}
+
 bool build_shape(const mrc_config& cfg, int a, int b, HostShape* out, std::string* err) {
     const int N = a + b;
     if (a <= 0 || b <= 0 || N % 4 != 0 || (b - a) % 4 != 0) {
@@ -137,18 +153,9 @@ bool build_shape(const mrc_config& cfg, int a, int b, HostShape* out, std::strin
     S.xiDen = ((double)N * (double)N) * (3. / 8.);
 
     // band table: psychoac.py:86-105 with the limits chosen at pacfileThem.py:637-645
-    const bool isLong = (N == 2 * cfg.n_mdct_lines);
-    const int* lim = isLong ? kLongLimits : kShortLimits;
-    const int nb = isLong ? 25 : 9;
-    std::vector<int> count(nb, 0);
-    {
-        int j = 0;
-        for (int i = 0; i < nb - 1; ++i) {
-            while (j < S.halfN && (j + 0.5) * (((double)cfg.sample_rate / S.halfN) / 2.) < lim[i]) { ++count[i]; ++j; }
-        }
-        count[nb - 1] = S.halfN - j;
-        if (count[nb - 1] < 0) { *err = "band table overflow"; return false; }
-    }
+    std::vector<int> count;
+    if (!band_table(cfg, a, b, &count)) { *err = "band table overflow"; return false; }
+    const int nb = (int)count.size();
     S.nBands = nb;
     out->bandN = count;
     out->bandLo.assign(nb, 0);

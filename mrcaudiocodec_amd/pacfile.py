@@ -1,0 +1,125 @@
+"""
+Host-side `.pac` writing for the encode path: the Huffman table choice and the bit packing run in C++
+(libmrc_hip.so: mrc_pack_blocks / mrc_pack_joint_blocks / mrc_pac_header, no GPU needed for them), fed
+with the dense arrays the GPU path returns.  Mirrors the encode half of the reference's file layer:
+
+    PACFile.WriteFileHeader      pacfileThem.py:586-619   -> header()
+    PACFile.WriteDataBlock       pacfileThem.py:622-790   -> pack_blocks()
+    PACFile.JointWriteDataBlock  pacfileThem.py:793-972   -> pack_joint_blocks()
+    the CLI's encode loop + Close pacfileThem.py:1159-1214, 973-984 -> encode_stereo_stream()
+
+Block shapes are an input (the transient detector is not part of this build).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, MrcConfig, MrcError
+
+_u8p = C.POINTER(C.c_uint8)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+
+
+def make_config(sample_rate=48000, n_mdct_lines=1024, n_short=128, n_scale_bits=4, n_mant_size_bits=4,
+                target_bits_per_sample=2.86, blksw_bits_a=1, blksw_bits_b=1):
+    cfg = MrcConfig()
+    lib.mrc_default_config(C.byref(cfg))
+    cfg.sample_rate, cfg.n_mdct_lines, cfg.n_short = int(sample_rate), int(n_mdct_lines), int(n_short)
+    cfg.n_scale_bits, cfg.n_mant_size_bits = int(n_scale_bits), int(n_mant_size_bits)
+    cfg.target_bits_per_sample = float(target_bits_per_sample)
+    cfg.blksw_bits_a, cfg.blksw_bits_b = int(blksw_bits_a), int(blksw_bits_b)
+    return cfg
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise MrcError("%s failed (%d)" % (what, rc))
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def band_table(cfg, a, b):
+    n = C.c_int32()
+    buf = np.zeros(_lib.MRC_MAX_BANDS, dtype=np.int32)
+    _check(lib.mrc_band_table(C.byref(cfg), int(a), int(b), C.byref(n), buf.ctypes.data_as(_i32p)), "mrc_band_table")
+    return buf[:n.value].copy()
+
+
+def header(cfg, n_channels, num_samples):
+    out = np.zeros(256, dtype=np.uint8)
+    n = C.c_int64()
+    _check(lib.mrc_pac_header(C.byref(cfg), int(n_channels), int(num_samples), out.ctypes.data_as(_u8p), out.size,
+                              C.byref(n)), "mrc_pac_header")
+    return out[:n.value].tobytes()
+
+
+def _run_pack(fn, cfg, n, nch, a, b, joint, args):
+    bound = lib.mrc_pack_bound(C.byref(cfg), int(a), int(b), nch, int(joint))
+    if bound < 0:
+        raise MrcError("mrc_pack_bound failed (%d)" % bound)
+    out = np.zeros(max(1, n * bound), dtype=np.uint8)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    table = np.zeros((n, nch), dtype=np.int32)
+    saved = np.zeros((n, nch), dtype=np.int32)
+    _check(fn(*args, out.ctypes.data_as(_u8p), out.size, offs.ctypes.data_as(_i64p), table.ctypes.data_as(_i32p),
+              saved.ctypes.data_as(_i32p)), fn.__name__)
+    return out[:offs[n]], offs, table, saved
+
+
+def pack_blocks(cfg, a, b, overall_scale, scale_factor, bit_alloc, mantissa, use_huffman=True):
+    """WriteDataBlock for n blocks of nch independent channels.  overall_scale [n][nch], scale_factor /
+    bit_alloc [n][nch][nBands], mantissa [n][nch][N/2] dense.  -> (bytes array, block offsets [n+1],
+    huffTable [n][nch], bits_saved [n][nch])."""
+    sf, ba, m = _i32(scale_factor), _i32(bit_alloc), _i32(mantissa)
+    osc = _i32(overall_scale)
+    n, nch = sf.shape[0], sf.shape[1]
+    args = (C.byref(cfg), n, nch, int(a), int(b), int(bool(use_huffman)), osc.ctypes.data_as(_i32p),
+            sf.ctypes.data_as(_i32p), ba.ctypes.data_as(_i32p), m.ctypes.data_as(_i32p))
+    return _run_pack(lib.mrc_pack_blocks, cfg, n, nch, a, b, 0, args)
+
+
+def pack_joint_blocks(cfg, a, b, overall_scale, ms_switch, scale_factor, bit_alloc, mantissa, use_huffman=True):
+    """JointWriteDataBlock for n blocks.  overall_scale [n][4], ms_switch [n][nBands], others [n][2][...]."""
+    sf, ba, m = _i32(scale_factor), _i32(bit_alloc), _i32(mantissa)
+    osc, sw = _i32(overall_scale), _i32(ms_switch)
+    n = sf.shape[0]
+    args = (C.byref(cfg), n, int(a), int(b), int(bool(use_huffman)), osc.ctypes.data_as(_i32p), sw.ctypes.data_as(_i32p),
+            sf.ctypes.data_as(_i32p), ba.ctypes.data_as(_i32p), m.ctypes.data_as(_i32p))
+    return _run_pack(lib.mrc_pack_joint_blocks, cfg, n, 2, a, b, 1, args)
+
+
+def encode_stereo_stream(handle, stream, shapes, use_huffman=True):
+    """The encode half of the reference CLI for a stereo stream [2][samples] that starts with the zero
+    prior hop and a given block-shape sequence [(offset, a, b)]: header, one joint block per shape with the
+    bit reservoir chained through the Huffman savings (codecThem.py:274,503), then Close()'s flush block
+    through the non-joint writer (pacfileThem.py:973-984).  Kernels on the GPU of `handle`, Huffman + bit
+    packing in C++ on the host.  Returns the .pac bytes."""
+    c = handle.cfg
+    cfg = make_config(c.sample_rate, c.n_mdct_lines, c.n_short, c.n_scale_bits, c.n_mant_size_bits,
+                      c.target_bits_per_sample, c.blksw_bits_a, c.blksw_bits_b)
+    L = c.n_mdct_lines
+    if shapes[-1][2] != L:
+        raise ValueError("the stream must end with a long block (the reference's Close() assumes it)")
+    stream = np.asarray(stream, dtype=np.float64)
+    out = [header(cfg, 2, sum(b for (_, _, b) in shapes))]
+    reservoir = 0
+    for (off, a, b) in shapes:
+        r = handle.encode_joint(stream[0, off:off + a + b][None, :], stream[1, off:off + a + b][None, :], a, b, [reservoir])
+        data, _, _, saved = pack_joint_blocks(cfg, a, b, r["overall_scale"], r["ms_switch"], r["scale_factor"],
+                                              r["bit_alloc"], r["mantissa"], use_huffman)
+        reservoir = int(r["reservoir_out"][0]) + int(saved.sum())
+        out.append(data.tobytes())
+    off, a, b = shapes[-1]
+    a = b
+    for ch in range(2):                                         # Close: codec.Encode, channel after channel
+        blk = np.concatenate([stream[ch, off + shapes[-1][1]:off + shapes[-1][1] + b], np.zeros(L)])[None, :]
+        r = handle.encode_mono(blk, a, L, [reservoir])
+        data, _, _, saved = pack_blocks(cfg, a, L, r["overall_scale"][:, None], r["scale_factor"][:, None, :],
+                                        r["bit_alloc"][:, None, :], r["mantissa"][:, None, :], use_huffman)
+        reservoir = int(r["reservoir_out"][0]) + int(saved.sum())
+        out.append(data.tobytes())
+    return b"".join(out)

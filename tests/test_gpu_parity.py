@@ -287,3 +287,26 @@ def test_device_stream_layout_matches_blocks(h):
     part = enc.encode_long(big[1024 * 1000:], None, 96)
     for k in _int_keys(False):
         assert torch.equal(full[k][1000:1096], part[k]), k
+
+
+# ------------------------------------------------------------------ bit-identical .pac bytes, chained reservoir
+@pytest.mark.parametrize("huff", [True, False])
+def test_pac_bytes_stereo_stream(h, huff):
+    # GPU kernels + C++ Huffman/bit packer vs the oracle's restatement of the reference's file layer:
+    # header, joint blocks with the reservoir chained through Huffman savings, block switching shapes,
+    # and Close()'s non-joint flush block.  Byte for byte.
+    from mrcaudiocodec_amd import pacfile as ppac, synth
+    from oracle import pacfile as opac
+    x, shapes = synth.c4_transients(11)                       # long, start, 8 short, stop, long ... ends long
+    g = synth.c2_noise(11, seed=9, sigma=0.05)
+    tone = synth.c1_sine(11)
+    stream = np.stack([x + 0.3 * tone, 0.7 * x + 0.3 * tone + 0.05 * g])
+    assert shapes[-1][2] == 1024
+    got = ppac.encode_stereo_stream(h, stream, shapes, use_huffman=huff)
+    want = opac.encode_stereo_stream(stream, shapes, huffman=huff)
+    assert len(got) == len(want)
+    assert got == want
+    # a pure tone pair drives the Huffman branch (tonal table) through the same path
+    t2 = np.stack([tone, 0.9 * tone])
+    shapes2 = [(i * 1024, 1024, 1024) for i in range(6)]
+    assert ppac.encode_stereo_stream(h, t2, shapes2, use_huffman=huff) == opac.encode_stereo_stream(t2, shapes2, huffman=huff)

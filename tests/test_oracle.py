@@ -265,3 +265,40 @@ def test_huffman_gain_escape_undercount_and_order():
     assert codes[2] == "101"
     m2 = np.array([16, 1, 1, 1, 1, 1, 1, 1, 1], dtype=np.int32)                       # 16 = percussive escape value
     assert codec.huffman_cost(m2, ba, cp.sfBands, *codec.TABLES["percussive"], 10 ** 9) == 6 + 8 * 4
+
+
+# ------------------------------------------------------------------ bit packer / .pac framing
+def test_bitpack_known_answer():
+    # bitpack.py:183-196: x = (3,5,11,3,1) in (4,3,5,3,1) bits -> 0011 101 0|1011 011 1
+    from oracle.pacfile import PackedBits
+    pb = PackedBits()
+    pb.Size(2)
+    for v, n in zip((3, 5, 11, 3, 1), (4, 3, 5, 3, 1)):
+        pb.WriteBits(v, n)
+    assert pb.GetPackedData() == bytes([0x3A, 0xB7])
+    pb.Size(3)
+    pb.WriteBits(0x1ABCD, 17)           # spans three bytes, only the low 17 bits of info are written
+    pb.WriteBits(0xFF, 0)
+    assert pb.GetPackedData() == bytes([0xD5, 0xE6, 0x80])
+
+
+def test_pac_stream_structure():
+    # header + one chunk pair per block + the non-joint flush block; every chunk length adds up
+    import struct
+    from mrcaudiocodec_amd import synth
+    from oracle import pacfile
+    s = synth.c3_stereo(3)
+    shapes = [(i * 1024, 1024, 1024) for i in range(3)]
+    data = pacfile.encode_stereo_stream(s, shapes)
+    assert data[:4] == b"PAC "
+    sr, nch, nsamp, nlines, sb, mb = struct.unpack("<LHLLHH", data[4:22])
+    assert (sr, nch, nlines, sb, mb) == (48000, 2, 1024, 4, 4) and nsamp == 3 * 1024 + 1024
+    nb, = struct.unpack("<L", data[22:26])
+    assert nb == 25
+    pos = 26 + 2 * nb
+    chunks = 0
+    while pos < len(data):
+        n, = struct.unpack("<L", data[pos:pos + 4])
+        pos += 4 + n
+        chunks += 1
+    assert pos == len(data) and chunks == 2 * (3 + 1)
