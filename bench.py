@@ -40,6 +40,19 @@ BYTES_ALLOC = 8192 + 4 + 25 * 8 + 4 + 4096 + 100 + 100 + 4   # lines, scale, SMR
 BYTES_PATH = 12496                                # hop in + all integer outputs
 
 
+def measured_traffic():
+    """HBM bytes per frame per kernel from the committed PMC summary (profiles/*_traffic.json: separate
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950 correction applied by
+    tools/summarize_profiles.py).  bench.py cannot collect PMC counters itself; {} when no summary exists."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return {}, None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    return {k: v["hbm_bytes_per_frame"] for k, v in d["kernels"].items()}, os.path.basename(files[-1])
+
+
 def make_noise_stream(torch, device, n_frames, seed):
     """C2 content generated on the device: 16-bit Gaussian PCM mapped to signed fractions
     (pcmfile.py:91-100), one leading hop of zeros (priorBlock at file start)."""
@@ -146,6 +159,10 @@ def main():
             kernels.append({"name": nm, "ms": round(float(ms), 4), "algorithmic_bytes": bpu * F,
                             "achieved_GBs": round(gbs, 2), "frac_hbm": round(gbs / HBM_PEAK_GBS, 5)})
         dom = int(np.argmax(stage_ms))
+        traffic, traffic_src = measured_traffic()
+        stage_kernels = [["mdct_long_kernel"], ["smr_kernel"], ["band_stats_kernel", "bitalloc_kernel", "quantize_kernel"]]
+        for kinfo, parts in zip(kernels, stage_kernels):
+            kinfo["traffic"] = round(sum(traffic[p] for p in parts) * F) if all(p in traffic for p in parts) else None
         line = {
             "metric": "encode Msamples/sec (48 kHz, 2048-pt MDCT)",
             "value": round(total_samples / elapsed / 1e6, 3),
@@ -159,9 +176,11 @@ def main():
                        "frames_per_gpu_per_step": F, "hop": HOP, "layout": "hop-overlapped f64 stream in HBM",
                        "parallelism": "frame-sharded x%d, no collective" % world},
             "roofline": {"kernel": names[dom], "bound": "hbm", "achieved": kernels[dom]["achieved_GBs"],
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[dom]["frac_hbm"], "traffic": None,
-                         "note": "dominant kernel by device time; the SMR kernel is limited by fp64 VALU "
-                                 "(10^x per masker x line), not by HBM -- see DESIGN.md"},
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[dom]["frac_hbm"],
+                         "traffic": kernels[dom]["traffic"], "traffic_source": traffic_src,
+                         "limiter": "fp64 VALU issue (2^x polynomial per masker x line), not HBM -- DESIGN.md section 4",
+                         "note": "dominant kernel by device time, priced against HBM as the contract asks; the "
+                                 "HBM-bound kernel of the path is mdct_long_kernel, see kernels[0]"},
             "kernels": kernels,
             "whole_path": {"algorithmic_bytes_per_frame": BYTES_PATH,
                            "achieved_GBs": round(BYTES_PATH * F * world * args.steps / elapsed / 1e9, 2)},

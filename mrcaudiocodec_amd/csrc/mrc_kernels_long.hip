@@ -123,9 +123,12 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void mdct_long_kernel(
     }
     __syncthreads();                                                   // pre/post tables visible to all waves
 
-    const int64_t firstUnit = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * kRun;
+    // The four waves of a workgroup take ADJACENT units at the same time (unit = base + 4*it + wave), so the
+    // hop two consecutive frames share (and, in joint mode, the L/R samples the four signals share) is
+    // fetched while it is still in L2: measured FETCH_SIZE falls from 2x to ~1x the algorithmic read.
+    const int64_t firstUnit = (int64_t)blockIdx.x * kWavesPerBlock * kRun + wave;
     for (int it = 0; it < kRun; ++it) {
-        const int64_t unit = firstUnit + it;
+        const int64_t unit = firstUnit + (int64_t)it * kWavesPerBlock;
         if (unit >= nUnits) break;                                     // wave-uniform
         const int64_t f = NSIG == 1 ? unit : unit / NSIG;
         const int sig = NSIG == 1 ? 0 : (int)(unit % NSIG);
