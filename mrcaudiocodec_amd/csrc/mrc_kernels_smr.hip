@@ -59,18 +59,35 @@ __device__ __forceinline__ double exp2_poly(double f) {
     return fma(p, f, 1.0);
 }
 
-// 2^t for finite t; t == 0 gives exactly 1 (a line inside +-1/2 Bark gets exactly the masker's intensity)
-// Requires |t| < 900 (here -230 < t <= 0): the integer part is taken from the low mantissa bits of
-// t + 1.5*2^52 and applied by adding it to the exponent field of the polynomial value (in [0.70, 1.42]),
-// which cannot leave the normal range for such t.
-__device__ __forceinline__ double exp2_fast(double t) {
+// 2^(s16*u/16) for the spreading loop, table driven: n = rint(s16*u) splits into k = n >> 4 (exponent),
+// j = n & 15 (entry of the 2^(j/16) table in LDS) and a remainder g = s16*u - n in [-1/2, 1/2] (exact, by
+// fma) whose 2^(g/16) is a degree-6 polynomial.  13 fp64 + 4 integer instructions per pair instead of 19 + 1;
+// max relative error ~3e-16.  s16*u == 0 gives exactly 1 (a line inside +-1/2 Bark gets exactly the masker's
+// intensity).  Requires |s16*u| < 2^20 (here it is < 4000): the exponent field of v cannot leave the normal range.
+__device__ __forceinline__ double exp2_tab16(double s16, double u, const double* __restrict__ tab) {
     const double shifter = 0x1.8p52;
-    const double tt = t + shifter;                       // low 32 mantissa bits = rint(t), two's complement
-    const double k = tt - shifter;
-    const double p = exp2_poly(t - k);
-    const int hi = __double2hiint(p) + (__double2loint(tt) << 20);
-    return __hiloint2double(hi, __double2loint(p));
+    const double tt = fma(s16, u, shifter);
+    const double r = tt - shifter;
+    const double g = fma(s16, u, -r);
+    const int n = __double2loint(tt);
+    double p = 0x1.430a49610efc6p-13 * 0x1p-24;          // coefficients of 2^f pre-divided by 16^j (f = g/16)
+    p = fma(p, g, 0x1.5d89be4c12513p-10 * 0x1p-20);
+    p = fma(p, g, 0x1.3b2ab6fb09b31p-7 * 0x1p-16);
+    p = fma(p, g, 0x1.c6b08d6e8a384p-5 * 0x1p-12);
+    p = fma(p, g, 0x1.ebfbdff82c594p-3 * 0x1p-8);
+    p = fma(p, g, 0x1.62e42fefa39fdp-1 * 0x1p-4);
+    p = fma(p, g, 1.0);
+    const double v = p * tab[n & 15];
+    const int hi = __double2hiint(v) + ((n >> 4) << 20);
+    return __hiloint2double(hi, __double2loint(v));
 }
+
+// 2^(j/16), j = 0..15, correctly rounded
+__constant__ double kExp2Sixteenths[16] = {
+    0x1.0000000000000p+0, 0x1.0b5586cf9890fp+0, 0x1.172b83c7d517bp+0, 0x1.2387a6e756238p+0,
+    0x1.306fe0a31b715p+0, 0x1.3dea64c123422p+0, 0x1.4bfdad5362a27p+0, 0x1.5ab07dd485429p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.7a11473eb0187p+0, 0x1.8ace5422aa0dbp+0, 0x1.9c49182a3f090p+0,
+    0x1.ae89f995ad3adp+0, 0x1.c199bdd85529cp+0, 0x1.d5818dcfba487p+0, 0x1.ea4afa2a490dap+0};
 
 // 2^(hi + lo), |lo| << 1
 __device__ __forceinline__ double exp2_dd(double hi, double lo) {
@@ -97,6 +114,7 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
     extern __shared__ double smem[];
     __shared__ int waveCnt[kThreads / kWave];
     __shared__ short pkBin[kMaxPeaks];                  // peak bins in increasing order
+    __shared__ double e2tab[16];                        // 2^(j/16)
     __shared__ unsigned long long bandKey[kMaxBands];   // per-band running max of the excess (order-preserving key)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6;
@@ -109,6 +127,7 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
     double* xi = smem + 4 * H;                          // [H] intensity spectrum (bins < peakLast used)
 
     if (tid < kMaxBands) bandKey[tid] = 0ull;           // below every key; visible after the first barrier
+    if (tid < 16) e2tab[tid] = kExp2Sixteenths[tid];
     // Hann window (window.py:28-45) and real FFT through an H = N/2 point complex FFT
     for (int n = tid; n < H; n += kThreads) {
         double e = load_signal(chL, chR, off + 2 * n, sig) * S.hann[2 * n];
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
                 const double ph = kLowHi * zm;
                 const double pl = fma(kLowHi, zm, -ph) + kLowLo * zm;
                 e[0] = I;
-                e[2] = ((-27 + boost) / 10) * kLog2Of10;
+                e[2] = (((-27 + boost) / 10) * kLog2Of10) * 16.0;          // upper slope, 1/16 bit per Bark
                 e[3] = I * exp2_dd(ph, pl);
             }
         }
@@ -305,13 +324,13 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
             for (int m = 0; m < mPlain; ++m) {
                 const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
                 const double u = fmax(zq - zm, 0.0);
-                tot = fma(I, exp2_fast(sl * u), tot);
+                tot = fma(I, exp2_tab16(sl, u, e2tab), tot);
             }
             // same, but part of the chunk lies below the masker's band (only when the chunk spans > 1 Bark)
             for (int m = mPlain; m < mExp; ++m) {
                 const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
                 const double u = fmax(zq - zm, 0.0);
-                tot = fma(m < cnt ? I : 0.0, exp2_fast(sl * u), tot);
+                tot = fma(m < cnt ? I : 0.0, exp2_tab16(sl, u, e2tab), tot);
             }
             // no line of the chunk is above the band: every line that sees the masker is inside +-1/2 Bark
             for (int m = mExp; m < mEnd; ++m) tot += (m < cnt) ? mt[4 * m] : 0.0;
