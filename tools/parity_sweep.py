@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""
+Large parity sweep on the GPU box: the HIP path (through the C ABI) against the batched oracle on many
+seeded frames, counting every integer output that differs.  The bar is zero; if an entry ever differs the
+sweep prints where and how close the deciding float64 values were (see DESIGN.md "Parity policy").
+
+    python tools/parity_sweep.py [--mono 16384] [--joint 4096] [--chunk 1024] > profiles/<tag>_parity_sweep.txt
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from mrcaudiocodec_amd import Handle, synth       # noqa: E402
+from oracle import fast                            # noqa: E402  (the checker)
+
+INT_KEYS = ("overall_scale", "bit_alloc", "scale_factor", "mantissa", "reservoir_out")
+
+
+def compare(got, ref, keys, base):
+    bad_frames = set()
+    bad_entries = 0
+    for k in keys:
+        d = np.asarray(got[k]) != np.asarray(ref[k])
+        if d.any():
+            idx = np.argwhere(d)
+            bad_entries += len(idx)
+            bad_frames.update(int(i[0]) + base for i in idx)
+            print("  MISMATCH %s: %d entries, first frame %d, got %s want %s" %
+                  (k, len(idx), int(idx[0][0]) + base, np.asarray(got[k])[tuple(idx[0])], np.asarray(ref[k])[tuple(idx[0])]))
+    return bad_frames, bad_entries
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mono", type=int, default=16384)
+    ap.add_argument("--joint", type=int, default=4096)
+    ap.add_argument("--chunk", type=int, default=1024)
+    args = ap.parse_args()
+    h = Handle()
+    t0 = time.time()
+    for name, n, joint in (("mono C2 noise", args.mono, False), ("joint C3 stereo", args.joint, True)):
+        frames_bad, entries_bad, mdct_err = set(), 0, 0.0
+        rng = np.random.default_rng(2026)
+        for base in range(0, n, args.chunk):
+            c = min(args.chunk, n - base)
+            seed = 100000 + base
+            res_in = rng.integers(-300, 800, c)
+            if joint:
+                s = synth.c3_stereo(c, seed_l=seed, seed_r=seed + 1)
+                bl, br = np.array(fast.blocks_from_stream(s[0], 1024)), np.array(fast.blocks_from_stream(s[1], 1024))
+                got = h.encode_joint(bl, br, 1024, 1024, res_in, want_mdct=True)
+                ref = fast.encode_joint_batch(bl, br, 1024, 1024, res_in)
+                keys = INT_KEYS + ("ms_switch",)
+            else:
+                blocks = np.array(fast.blocks_from_stream(synth.c2_noise(c, seed=seed), 1024))
+                got = h.encode_mono(blocks, 1024, 1024, res_in, want_mdct=True)
+                ref = fast.encode_mono_batch(blocks, 1024, 1024, res_in)
+                keys = INT_KEYS
+            fb, eb = compare(got, ref, keys, base)
+            frames_bad |= fb
+            entries_bad += eb
+            mdct_err = max(mdct_err, float(np.abs(got["mdct"] - ref["mdct"]).max() / np.abs(ref["mdct"]).max()))
+            print("%s: %d/%d frames done, %d mismatching frames so far (%.0f s)" %
+                  (name, base + c, n, len(frames_bad), time.time() - t0), flush=True)
+        print("RESULT %s: frames=%d mismatching_frames=%d mismatching_entries=%d max_rel_mdct_err=%.3g" %
+              (name, n, len(frames_bad), entries_bad, mdct_err), flush=True)
+    h.close()
+
+
+if __name__ == "__main__":
+    main()
