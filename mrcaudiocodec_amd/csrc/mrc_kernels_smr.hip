@@ -38,6 +38,14 @@ __device__ __forceinline__ double order_value(unsigned long long k) {
     unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
     return __longlong_as_double((long long)b);
 }
+// far-field local expansion (see the sweep): order, widest group of lines (Bark), fewest maskers worth it
+constexpr int kFarOrder = 16;
+constexpr double kFarSpan = 0.225;
+constexpr int kFarMinMaskers = 48;
+constexpr double kInvFactorial[kFarOrder + 1] = {
+    1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
+    1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0, 1.0 / 87178291200.0,
+    1.0 / 1307674368000.0, 1.0 / 20922789888000.0};
 constexpr double kLog2Of10 = 0x1.a934f0979a371p+1;
 // b = -2.7*log2(10) bits per Bark below the masker (psychoac.py:74), split hi + lo
 constexpr double kLowHi = -0x1.1f03bbffee7edp+3;
@@ -319,9 +327,60 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
 #endif
             const int mPlain = min(mExp, mLow);
             const double zq = z - 0.5;                 // u = max(z - z_m - 1/2, 0), one subtraction per pair
+
+            // ---- far field by local expansion.  Maskers [0, nFar) lie more than 1/2 Bark below EVERY line
+            // of the chunk, so their sum  sum_m I_m 2^(s_m (z - z_m - 1/2))  is smooth in z over the chunk:
+            // with a = s_m ln2 and d = z - c (c = centre of a group of lines),
+            //   sum_m e_m exp(a_m d) = sum_j d^j/j! * B_j,   B_j = sum_m e_m a_m^j,   e_m = I_m 2^(s_m (c - z_m - 1/2)).
+            // Lanes take maskers (one 2^x per masker and group instead of one per masker and LINE), B_j is
+            // wave-reduced, every line evaluates the degree-J polynomial.  |a| <= 8.97 ln2 and |d| <= kFarSpan/2
+            // give |a d| <= 0.7: the truncated tail is < 1.3e-17 of each term (relative, term by term).
+            int mFirst = 0;
+#ifndef MRC_PROFILE_SKIP_SPREAD
+            {
+                const double zFirst = __shfl(z, 0), zLast = __shfl(z, kWave - 1);
+                const double zHalfEnd = __shfl(z, kWave / 2 - 1), zHalfBeg = __shfl(z, kWave / 2);
+                const int nFar = __builtin_amdgcn_readfirstlane(nUp);          // nUp of the chunk's first line
+                int nGroups = 0;
+                if (zLast - zFirst <= kFarSpan) nGroups = 1;
+                else if (zHalfEnd - zFirst <= kFarSpan && zLast - zHalfBeg <= kFarSpan) nGroups = 2;
+                if (nGroups && nFar >= kFarMinMaskers) {
+                    const int myGroup = (nGroups == 2) ? (lane >> 5) : 0;
+                    for (int g = 0; g < nGroups; ++g) {
+                        const double c = (nGroups == 1) ? 0.5 * (zFirst + zLast)
+                                                        : (g == 0 ? 0.5 * (zFirst + zHalfEnd) : 0.5 * (zHalfBeg + zLast));
+                        const double cq = c - 0.5;
+                        double B[kFarOrder + 1];
+#pragma unroll
+                        for (int j = 0; j <= kFarOrder; ++j) B[j] = 0.0;
+                        for (int m = lane; m < nFar; m += kWave) {
+                            const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
+                            double term = I * exp2_tab16(sl, cq - zm, e2tab);          // cq - zm > 0 for m < nFar
+                            const double a = sl * (0.6931471805599453094 / 16.0);     // slope in nats per Bark
+#pragma unroll
+                            for (int j = 0; j <= kFarOrder; ++j) {
+                                B[j] += term;
+                                term *= a;
+                            }
+                        }
+                        const double d = z - c;
+                        double p = 0.0;
+#pragma unroll
+                        for (int j = kFarOrder; j >= 0; --j) {
+                            double s = B[j];
+#pragma unroll
+                            for (int offl = 32; offl > 0; offl >>= 1) s += __shfl_xor(s, offl);
+                            p = fma(p, d, s * kInvFactorial[j]);
+                        }
+                        if (g == myGroup) tot += p;
+                    }
+                    mFirst = nFar;
+                }
+            }
+#endif
             // some line of the chunk is above the masker's band, every line sees the masker
 #pragma unroll 4
-            for (int m = 0; m < mPlain; ++m) {
+            for (int m = mFirst; m < mPlain; ++m) {
                 const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
                 const double u = fmax(zq - zm, 0.0);
                 tot = fma(I, exp2_tab16(sl, u, e2tab), tot);
