@@ -112,8 +112,8 @@ int mrc_create(const mrc_config* cfg, mrc_handle** out) {
     if (!cfg || !out) return fail(nullptr, MRC_ERR_INVALID, "mrc_create: null argument");
     *out = nullptr;
     if (cfg->sample_rate <= 0 || cfg->n_mdct_lines <= 0 || cfg->n_short <= 0 || cfg->n_scale_bits < 1 ||
-        cfg->n_scale_bits > 4 || cfg->n_mant_size_bits < 1 || cfg->n_mant_size_bits > 4)
-        return fail(nullptr, MRC_ERR_INVALID, "mrc_create: parameter out of range (nScaleBits, nMantSizeBits in 1..4)");
+        cfg->n_scale_bits > 4 || cfg->n_mant_size_bits < 1 || cfg->n_mant_size_bits > 8)
+        return fail(nullptr, MRC_ERR_INVALID, "mrc_create: parameter out of range (nScaleBits in 1..4, nMantSizeBits in 1..8)");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)

@@ -26,7 +26,6 @@ using namespace dev;
 namespace {
 
 constexpr int kLinesPerThread = 4;                     // EXACT mode register tile
-constexpr int kMaxPeaks = 1024;                        // peaks <= (N/2-100)/2: enough for N <= 4096
 
 // Order-preserving map double -> uint64 (a < b  <=>  key(a) < key(b), -0 < +0), so that a maximum over
 // doubles can be taken with an integer LDS atomic.
@@ -46,7 +45,8 @@ constexpr double kInvFactorial[kFarOrder + 1] = {
     1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
     1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0, 1.0 / 87178291200.0,
     1.0 / 1307674368000.0, 1.0 / 20922789888000.0};
-constexpr double kLog2Of10 = 0x1.a934f0979a371p+1;
+constexpr double kLog2Of10 = 0x1.a934f0979a371p+1;     // log2(10) = hi + lo
+constexpr double kLog2Of10Lo = 0x1.7f2495fb7fa6dp-53;
 // b = -2.7*log2(10) bits per Bark below the masker (psychoac.py:74), split hi + lo
 constexpr double kLowHi = -0x1.1f03bbffee7edp+3;
 constexpr double kLowLo = 0x1.e3c74df63d090p-51;
@@ -121,7 +121,6 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
                                                        double* __restrict__ thresh) {
     extern __shared__ double smem[];
     __shared__ int waveCnt[kThreads / kWave];
-    __shared__ short pkBin[kMaxPeaks];                  // peak bins in increasing order
     __shared__ double e2tab[16];                        // 2^(j/16)
     __shared__ unsigned long long bandKey[kMaxBands];   // per-band running max of the excess (order-preserving key)
     const int tid = threadIdx.x;
@@ -132,7 +131,11 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
     const int64_t off = offsets ? offsets[f] : f * stride;
     double2* A = (double2*)smem;                        // [H]
     double2* B = A + H;                                 // [H]
-    double* xi = smem + 4 * H;                          // [H] intensity spectrum (bins < peakLast used)
+    double* xi = smem + 4 * H;                          // [peakLast + 1] intensity spectrum; later the suffix sums
+    // region B is free once the spectrum is in xi: peak bins, then per-line masker counts (filled below)
+    short* pkBin = reinterpret_cast<short*>(smem + 2 * H);              // [<= peakLast/2 + 1] peak bins, increasing
+    unsigned short* cntArr = reinterpret_cast<unsigned short*>(pkBin + ((S.peakLast / 2 + 3) & ~1));   // [M + 1]
+    unsigned short* nUpArr = cntArr + (M + 2);                           // [M + 1]
 
     if (tid < kMaxBands) bandKey[tid] = 0ull;           // below every key; visible after the first barrier
     if (tid < 16) e2tab[tid] = kExp2Sixteenths[tid];
@@ -182,6 +185,8 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
     // table entry is computed by full waves instead of the few lanes that happen to own a peak
     for (int p = p0; p < p1; ++p)
         if (xi[p] > xi[p - 1] && xi[p] > xi[p + 1]) pkBin[before++] = (short)p;
+    if (!EXACT)
+        for (int k = tid; k <= M; k += kThreads) { cntArr[k] = 0; nUpArr[k] = 0; }
     __syncthreads();
     for (int mi = tid; mi < nPeaks; mi += kThreads) {
         const int p = pkBin[mi];
@@ -201,12 +206,29 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
                 e[0] = lvl15;
                 e[2] = boost;
             } else {
-                const double I = pow(10.0, (lvl15 - 96) / 10);               // psychoac.py:14-18
+                // psychoac.py:14-18: 10^((spl-96)/10) as 2^(x log2 10), exponent in double-double (<= 1 ulp)
+                const double xe = (lvl15 - 96) / 10;
+                const double eh = xe * kLog2Of10;
+                const double I = exp2_dd(eh, fma(xe, kLog2Of10, -eh) + xe * kLog2Of10Lo);
                 const double ph = kLowHi * zm;
                 const double pl = fma(kLowHi, zm, -ph) + kLowLo * zm;
                 e[0] = I;
                 e[2] = (((-27 + boost) / 10) * kLog2Of10) * 16.0;          // upper slope, 1/16 bit per Bark
                 e[3] = I * exp2_dd(ph, pl);
+                // first line that sees this masker at all (fl(z_k - z_m) >= -1/2) and first line more than
+                // 1/2 Bark above it (fl(z_k - z_m) > 1/2): both predicates are monotone in k
+                int lo = 0, hi = M;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (S.zb[mid] - zm >= -0.5) hi = mid; else lo = mid + 1;
+                }
+                atomicAdd(reinterpret_cast<unsigned int*>(cntArr) + (lo >> 1), 1u << (16 * (lo & 1)));
+                hi = M;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (S.zb[mid] - zm > 0.5) hi = mid; else lo = mid + 1;
+                }
+                atomicAdd(reinterpret_cast<unsigned int*>(nUpArr) + (lo >> 1), 1u << (16 * (lo & 1)));
             }
         }
     }
@@ -280,6 +302,25 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
             }
             if (lane == 0) sc[nPeaks] = 0.0;
         }
+        // per-line masker counts: inclusive prefix sums of the two histograms the table build left
+        // (cnt[k] = maskers with fl(z_k - z_m) >= -1/2, nUp[k] = maskers with fl(z_k - z_m) > 1/2)
+        {
+            const int per2 = (M + kThreads) / kThreads;                     // entries per thread, covers 0..M
+            const int k0 = tid * per2, k1 = min(k0 + per2, M + 1);
+            unsigned int sc2 = 0, su2 = 0;
+            for (int k = k0; k < k1; ++k) { sc2 += cntArr[k]; su2 += nUpArr[k]; }
+            unsigned int packed = sc2 | (su2 << 16);                         // both sums < 2^16
+            const unsigned int inclP = (unsigned int)wave_incl_scan((int)packed, lane);
+            if (lane == kWave - 1) waveCnt[wave] = (int)inclP;
+            __syncthreads();
+            unsigned int base = inclP - packed;
+            for (int w = 0; w < wave; ++w) base += (unsigned int)waveCnt[w];
+            unsigned int rc = base & 0xffffu, ru = base >> 16;
+            for (int k = k0; k < k1; ++k) {
+                rc += cntArr[k]; ru += nUpArr[k];
+                cntArr[k] = (unsigned short)rc; nUpArr[k] = (unsigned short)ru;
+            }
+        }
         __syncthreads();
 
         // Each wave sweeps 64-line chunks (one line per lane); the chunk order pairs cheap (low) with
@@ -297,21 +338,7 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
             const int kc = min(k, M - 1);
             const double z = S.zb[kc];
             double tot = S.quiet[kc];
-            int cnt, nUp;
-            {
-                int lo = 0, hi = nPeaks;                // maskers with fl(z - z_m) >= -1/2
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (z - mt[4 * mid + 1] >= -0.5) lo = mid + 1; else hi = mid;
-                }
-                cnt = lo;
-                lo = 0; hi = cnt;                       // maskers with fl(z - z_m) > 1/2
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (z - mt[4 * mid + 1] > 0.5) lo = mid + 1; else hi = mid;
-                }
-                nUp = lo;
-            }
+            const int cnt = cntArr[kc], nUp = nUpArr[kc];      // maskers that reach the line / lie > 1/2 Bark below it
             int mLow = cnt, mEnd = cnt, mExp = nUp;
 #pragma unroll
             for (int offl = 32; offl > 0; offl >>= 1) {
@@ -421,7 +448,7 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const double* chL, con
                       bool exactSpread, hipStream_t st) {
     if (nFrames <= 0) return hipSuccess;
     const int nsig = chR ? 4 : 1;
-    size_t lds = (size_t)(5 * S.H) * sizeof(double);
+    size_t lds = (size_t)(4 * S.H + S.peakLast + 1) * sizeof(double);
     if (exactSpread)
         hipLaunchKernelGGL(smr_kernel<true>, dim3((unsigned)(nFrames * nsig)), dim3(kThreads), lds, st, S, nsig, chL,
                            chR, stride, offsets, lines, oscale, smr, thresh);

@@ -148,7 +148,7 @@ inline void put_u32le(uint8_t* p, uint32_t v) { p[0] = v & 255; p[1] = (v >> 8) 
 
 bool shape_ok(const mrc_config* cfg, int a, int b) {
     return cfg && a > 0 && b > 0 && (a + b) % 2 == 0 && cfg->n_mdct_lines > 0 && cfg->n_scale_bits >= 1 &&
-           cfg->n_scale_bits <= 4 && cfg->n_mant_size_bits >= 1 && cfg->n_mant_size_bits <= 4;
+           cfg->n_scale_bits <= 4 && cfg->n_mant_size_bits >= 1 && cfg->n_mant_size_bits <= 8;
 }
 
 }  // namespace

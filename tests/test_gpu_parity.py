@@ -310,3 +310,22 @@ def test_pac_bytes_stereo_stream(h, huff):
     t2 = np.stack([tone, 0.9 * tone])
     shapes2 = [(i * 1024, 1024, 1024) for i in range(6)]
     assert ppac.encode_stereo_stream(h, t2, shapes2, use_huffman=huff) == opac.encode_stereo_stream(t2, shapes2, huffman=huff)
+
+
+# ------------------------------------------------------------------ other codec parameters
+def test_training_script_parameters_44k():
+    # huffman_training_script.py:39-45: nScaleBits 3, nMantSizeBits 5, 2.27 bits/sample -- at 44.1 kHz the
+    # py2 integer division sampleRate/N is 21 and the band tables differ from the 48 kHz ones
+    from mrcaudiocodec_amd import Handle, synth
+    P = dict(sampleRate=44100, nScaleBits=3, nMantSizeBits=5, targetBitsPerSample=2.27)
+    hd = Handle(sample_rate=44100, n_scale_bits=3, n_mant_size_bits=5, target_bits_per_sample=2.27)
+    try:
+        for (a, b) in SHAPES:
+            assert list(hd.bands(a, b)) == [int(v) for v in fast.bands_for(a, b, 1024, 44100).nLines]
+            blocks = _noise_blocks(a, b, 96, seed=7, sigma=0.2)
+            _assert_int_parity(hd.encode_mono(blocks, a, b), fast.encode_mono_batch(blocks, a, b, params=P))
+        s = synth.c3_stereo(64)
+        bl, br = np.array(fast.blocks_from_stream(s[0], 1024)), np.array(fast.blocks_from_stream(s[1], 1024))
+        _assert_int_parity(hd.encode_joint(bl, br, 1024, 1024), fast.encode_joint_batch(bl, br, 1024, 1024, params=P), joint=True)
+    finally:
+        hd.close()
