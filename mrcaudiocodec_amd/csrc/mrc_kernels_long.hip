@@ -1,14 +1,19 @@
 // Long-block (a = b = 1024, N = 2048) specialisation of the windowed MDCT for gfx950.
 //
-// One 64-lane wavefront owns one (frame, signal) at a time and walks a run of consecutive units, so a
-// hop that two consecutive frames share is fetched from HBM once and from L2 the second time.  The
-// 512-point complex FFT inside the N/4 MDCT algorithm is three radix-8 Stockham passes: 8 points per
-// lane in registers, two lane exchanges through LDS (the first one padded by one slot per 8 so that the
-// stride-8 writes stay conflict-free), no workgroup barrier anywhere -- only wave-local ordering.
-// Window values and inter-pass twiddles of a lane never change from frame to frame and live in
-// registers; pre-/post-twiddles sit in LDS, shared by the four waves of the workgroup.
-// HBM traffic per unit is the algorithmic 8 KiB in + 8 KiB out: loads are 16 B per lane over 1 KiB
-// contiguous, stores likewise after an LDS transpose of the even/odd output interleave.
+// One 64-lane wavefront owns one (frame, signal) at a time.  The 512-point complex FFT inside the N/4 MDCT
+// algorithm is three radix-8 Stockham passes: 8 points per lane in registers, two lane exchanges through
+// LDS (the first one padded by one slot per 8 so that the stride-8 writes stay conflict-free), no workgroup
+// barrier in the loop -- only wave-local ordering.  Window values of a lane never change from frame to
+// frame and live in registers; the W512 twiddle table sits in LDS, shared by the four waves; pre- and
+// post-twiddles factor as (lane constant) x W32^r with compile-time W32 powers.
+//
+// HBM traffic.  Loads are 16 B per lane over 1 KiB contiguous, stores likewise after an LDS transpose of
+// the even/odd output interleave.  Two unit orders:
+//   REUSE (mono, hop-overlapped stream): a wave walks kRun CONSECUTIVE frames and keeps the raw second half
+//     of its block in registers -- it is the first half of the next block -- so every hop is loaded once:
+//     8 KiB in + 8 KiB out per frame, the algorithmic minimum (plus one extra hop per run of kRun frames).
+//   otherwise (joint stereo, explicit blocks): the four waves of a workgroup take ADJACENT units at the same
+//     time, so what they share (the overlapping hop; the L/R samples of the four signals) is still in L2.
 //
 // Arithmetic: same formulas as the generic mdct_kernel (window.py:104-121, mdct.py:63-76,
 // codecThem.py:321-322), float64, file compiled with -ffp-contract=off.
@@ -19,9 +24,9 @@ namespace {
 
 constexpr int kWave = 64;
 constexpr int kWavesPerBlock = 4;
-constexpr int kM = 1024, kQ = 512;                 // N = 2048: N/2 lines, N/4-point FFT
+constexpr int kM = 1024, kQ = 512;                   // N = 2048: N/2 lines, N/4-point FFT
 constexpr int kWaveLds = 2048;                       // doubles per wave (16 KiB)
-constexpr int kRun = 16;                             // consecutive units per wave
+constexpr int kRun = 16;                             // units per wave
 
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
@@ -29,6 +34,14 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }     // a * (-i)
+
+// a * e^{-2 pi i R/32}, R = 1..7 (compile-time)
+template <int R> __device__ __forceinline__ double2 mul_w32(double2 a) {
+    constexpr double c[8] = {1.0, 0.98078528040323044913, 0.92387953251128675613, 0.83146961230254523708,
+                             0.70710678118654752440, 0.55557023301960222474, 0.38268343236508977173,
+                             0.19509032201612826785};
+    return cmul(a, make_double2(c[R], -c[8 - R]));                   // sin(2 pi R/32) = cos(2 pi (8-R)/32)
+}
 
 // LDS traffic between lanes of ONE wave: order the wave's own DS operations and stop the compiler from
 // moving LDS accesses across this point.  No other wave is involved.
@@ -94,45 +107,52 @@ __device__ __forceinline__ void load_pair(const double* __restrict__ L, const do
     }
 }
 
-template <int NSIG>
+// pre[lane + 64 r] = pre[lane] * W32^r and post[lane + 64 q] = post[lane] * W32^q (both tables are unit-circle
+// points whose angle is affine in the index with step 2 pi/2048 resp. 4 * 2 pi/4096 per index)
+template <int R> __device__ __forceinline__ double2 twiddle_lane(double2 v, double2 laneConst) {
+    double2 t = cmul(v, laneConst);
+    if (R == 0) return t;
+    return mul_w32<R == 0 ? 1 : R>(t);
+}
+
+template <int NSIG, bool REUSE>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void mdct_long_kernel(
     DevShape S, int64_t nUnits, const double* __restrict__ chL, const double* __restrict__ chR, int64_t stride,
-    const int64_t* __restrict__ offsets, double* __restrict__ lines, int* __restrict__ oscale) {
-    __shared__ __attribute__((aligned(16))) double smem[kWavesPerBlock * kWaveLds + 4 * kQ];
+    double* __restrict__ lines, int* __restrict__ oscale) {
+    __shared__ __attribute__((aligned(16))) double smem[kWavesPerBlock * kWaveLds + 2 * kQ];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
     double* ws = smem + wave * kWaveLds;                               // this wave's 16 KiB
-    double2* preL = reinterpret_cast<double2*>(smem + kWavesPerBlock * kWaveLds);   // [512]
-    double2* postL = preL + kQ;                                        // [512]
-    for (int i = threadIdx.x; i < kQ; i += kWave * kWavesPerBlock) {
-        preL[i] = S.pre[i];
-        postL[i] = S.post[i];
-    }
-    // lane-constant registers: window at the lane's sample pairs, twiddles of passes 2 and 3
+    double2* w512 = reinterpret_cast<double2*>(smem + kWavesPerBlock * kWaveLds);   // [512] e^{-2 pi i t/512}
+    for (int i = threadIdx.x; i < kQ; i += kWave * kWavesPerBlock) w512[i] = S.wQ[i];
+    // lane-constant registers: window at the lane's sample pairs; pre/post twiddle of the lane's first point
     double wE[16], wO[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
         double2 w = *reinterpret_cast<const double2*>(S.win + 2 * (lane + 64 * c));
         wE[c] = w.x; wO[c] = w.y;
     }
-    double2 tw2[7], tw3[7];
-#pragma unroll
-    for (int r = 1; r < 8; ++r) {
-        tw2[r - 1] = S.wQ[8 * (lane & 7) * r];                         // W512^(8 k r), k = lane % 8
-        tw3[r - 1] = S.wQ[lane * r];                                   // W512^(lane r)
-    }
-    __syncthreads();                                                   // pre/post tables visible to all waves
+    const double2 preLane = S.pre[lane];
+    const double2 postLane = S.post[lane];
+    __syncthreads();                            // W512 table visible to all waves
 
-    // The four waves of a workgroup take ADJACENT units at the same time (unit = base + 4*it + wave), so the
-    // hop two consecutive frames share (and, in joint mode, the L/R samples the four signals share) is
-    // fetched while it is still in L2: measured FETCH_SIZE falls from 2x to ~1x the algorithmic read.
-    const int64_t firstUnit = (int64_t)blockIdx.x * kWavesPerBlock * kRun + wave;
+    int64_t firstUnit, step;
+    if (REUSE) { firstUnit = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * kRun; step = 1; }
+    else { firstUnit = (int64_t)blockIdx.x * kWavesPerBlock * kRun + wave; step = kWavesPerBlock; }
+
+    double rawE[8], rawO[8];                    // REUSE: raw second half of the previous block (= first half of this one)
+    if (REUSE && firstUnit < nUnits) {
+        const int64_t off = firstUnit * stride;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) load_pair<1>(chL, chR, off + 2 * (lane + 64 * c), 0, &rawE[c], &rawO[c]);
+    }
+
     for (int it = 0; it < kRun; ++it) {
-        const int64_t unit = firstUnit + (int64_t)it * kWavesPerBlock;
+        const int64_t unit = firstUnit + (int64_t)it * step;
         if (unit >= nUnits) break;                                     // wave-uniform
         const int64_t f = NSIG == 1 ? unit : unit / NSIG;
         const int sig = NSIG == 1 ? 0 : (int)(unit % NSIG);
-        const int64_t off = offsets ? offsets[f] : f * stride;
+        const int64_t off = f * stride;
 
         // ---- A. coalesced load (16 B per lane), window, de-interleave into yE / yO
         double* yE = ws;
@@ -141,26 +161,28 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void mdct_long_kernel(
         for (int c = 0; c < 16; ++c) {
             const int i = lane + 64 * c;
             double e, o;
-            load_pair<NSIG>(chL, chR, off + 2 * i, sig, &e, &o);
+            if (REUSE && c < 8) {
+                e = rawE[c]; o = rawO[c];
+            } else {
+                load_pair<NSIG>(chL, chR, off + 2 * i, sig, &e, &o);
+                if (REUSE) { rawE[c & 7] = e; rawO[c & 7] = o; }
+            }
             yE[i] = e * wE[c];
             yO[i] = o * wO[c];
         }
         wave_sync();
         // ---- B. fold N -> N/2 -> 512 complex points (n = lane + 64 r), pre-twiddle
         double2 u[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int n = lane + 64 * r;
-            double re, im;
-            if (r < 4) {           // n < 256
-                re = -yO[767 - n] - yE[768 + n];
-                im = yO[255 - n] - yE[256 + n];
-            } else {
-                re = yE[n - 256] - yO[767 - n];
-                im = -yE[256 + n] - yO[1279 - n];
-            }
-            u[r] = cmul(make_double2(re, im), preL[n]);
+#define MRC_FOLD(R)                                                                     \
+        {                                                                               \
+            const int n = lane + 64 * R;                                                \
+            double re, im;                                                              \
+            if (R < 4) { re = -yO[767 - n] - yE[768 + n]; im = yO[255 - n] - yE[256 + n]; }          \
+            else { re = yE[n - 256] - yO[767 - n]; im = -yE[256 + n] - yO[1279 - n]; }  \
+            u[R] = twiddle_lane<R>(make_double2(re, im), preLane);                      \
         }
+        MRC_FOLD(0) MRC_FOLD(1) MRC_FOLD(2) MRC_FOLD(3) MRC_FOLD(4) MRC_FOLD(5) MRC_FOLD(6) MRC_FOLD(7)
+#undef MRC_FOLD
         wave_sync();               // all gathers done before the region is reused
         // ---- C. FFT-512 = 8 x 8 x 8
         dft8(u);
@@ -172,7 +194,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void mdct_long_kernel(
         for (int r = 0; r < 8; ++r) u[r] = ex[lane + (lane >> 3) + 72 * r];   // element lane + 64 r
         wave_sync();
 #pragma unroll
-        for (int r = 1; r < 8; ++r) u[r] = cmul(u[r], tw2[r - 1]);
+        for (int r = 1; r < 8; ++r) u[r] = cmul(u[r], w512[8 * (lane & 7) * r]);     // W512^(8 k r), k = lane % 8
         dft8(u);
         {
             const int base = 64 * (lane >> 3) + (lane & 7);
@@ -184,22 +206,24 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void mdct_long_kernel(
         for (int r = 0; r < 8; ++r) u[r] = ex[lane + 64 * r];
         wave_sync();
 #pragma unroll
-        for (int r = 1; r < 8; ++r) u[r] = cmul(u[r], tw3[r - 1]);
+        for (int r = 1; r < 8; ++r) u[r] = cmul(u[r], w512[lane * r]);               // W512^(lane r)
         dft8(u);                                                        // u[q] = T[lane + 64 q]
         // ---- D. post-twiddle, X[2k] = (2/N) Re, X[N/2-1-2k] = -(2/N) Im, transpose through LDS
         double* xE = ws;                                                // xE[i] = X[2i]
         double* xO = ws + kQ;                                           // xO[i] = X[2i+1]
         double peak = 0.0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int k = lane + 64 * q;
-            double2 c = cmul(u[q], postL[k]);
-            double a = S.twoOverN * c.x;
-            double b = S.twoOverN * (-c.y);
-            xE[k] = a;
-            xO[511 - k] = b;                                            // line 1023-2k = 2*(511-k)+1
-            peak = fmax(peak, fmax(fabs(a), fabs(b)));
+#define MRC_POST(Q)                                                                     \
+        {                                                                               \
+            const int k = lane + 64 * Q;                                                \
+            const double2 c = twiddle_lane<Q>(u[Q], postLane);                          \
+            const double a = S.twoOverN * c.x;                                          \
+            const double b = S.twoOverN * (-c.y);                                       \
+            xE[k] = a;                                                                  \
+            xO[511 - k] = b;                        /* line 1023-2k = 2*(511-k)+1 */     \
+            peak = fmax(peak, fmax(fabs(a), fabs(b)));                                  \
         }
+        MRC_POST(0) MRC_POST(1) MRC_POST(2) MRC_POST(3) MRC_POST(4) MRC_POST(5) MRC_POST(6) MRC_POST(7)
+#undef MRC_POST
         wave_sync();
         double* dst = lines + unit * kM;
 #pragma unroll
@@ -231,12 +255,16 @@ hipError_t launch_mdct_long(const DevShape& S, int64_t nFrames, const double* ch
     const int64_t nUnits = nFrames * nsig;
     const int64_t perBlock = (int64_t)kWavesPerBlock * kRun;
     const unsigned grid = (unsigned)((nUnits + perBlock - 1) / perBlock);
-    if (nsig == 1)
-        hipLaunchKernelGGL(mdct_long_kernel<1>, dim3(grid), dim3(kWave * kWavesPerBlock), 0, st, S, nUnits, chL, chR,
-                           stride, nullptr, lines, oscale);
+    const dim3 block(kWave * kWavesPerBlock);
+    if (nsig == 4)
+        hipLaunchKernelGGL((mdct_long_kernel<4, false>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, lines,
+                           oscale);
+    else if (stride == kM)                           // hop-overlapped stream: consecutive frames share a hop
+        hipLaunchKernelGGL((mdct_long_kernel<1, true>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, lines,
+                           oscale);
     else
-        hipLaunchKernelGGL(mdct_long_kernel<4>, dim3(grid), dim3(kWave * kWavesPerBlock), 0, st, S, nUnits, chL, chR,
-                           stride, nullptr, lines, oscale);
+        hipLaunchKernelGGL((mdct_long_kernel<1, false>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, lines,
+                           oscale);
     return hipGetLastError();
 }
 
