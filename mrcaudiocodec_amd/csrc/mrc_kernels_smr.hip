@@ -103,6 +103,54 @@ __device__ __forceinline__ double exp2_dd(double hi, double lo) {
     return ldexp(exp2_poly((hi - k) + lo), (int)k);
 }
 
+// (hi, lo) += (xh, xl) in double-double (Knuth two-sum on the high parts; |lo| << |hi|)
+__device__ __forceinline__ void dd_add(double* hi, double* lo, double xh, double xl) {
+    const double s = *hi + xh;
+    const double v = s - *hi;
+    double e = (*hi - (s - v)) + (xh - v);
+    e += *lo + xl;
+    const double h = s + e;
+    *lo = e - (h - s);
+    *hi = h;
+}
+
+// Sum each of 16 per-lane values over the 64 lanes of the wave and leave all 16 totals in every lane.
+// A "transposing" butterfly: at distance 32, 16, 8, 4 every lane hands HALF of its remaining values to its
+// partner and adds the partner's half of the others (8 + 4 + 2 + 1 exchanges instead of 16 x 6), which
+// leaves lane l with the partial sum of value number (l >> 2) & 15; two plain butterfly steps finish it and
+// 16 broadcasts distribute the totals.
+__device__ __forceinline__ void wave_sum_16(double* v, int lane) {
+    double w[8];
+    const bool h5 = lane & 32;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double send = h5 ? v[i] : v[i + 8];
+        const double keep = h5 ? v[i + 8] : v[i];
+        w[i] = keep + __shfl_xor(send, 32);
+    }
+    const bool h4 = lane & 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double send = h4 ? w[i] : w[i + 4];
+        const double keep = h4 ? w[i + 4] : w[i];
+        w[i] = keep + __shfl_xor(send, 16);
+    }
+    const bool h3 = lane & 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double send = h3 ? w[i] : w[i + 2];
+        const double keep = h3 ? w[i + 2] : w[i];
+        w[i] = keep + __shfl_xor(send, 8);
+    }
+    const bool h2 = lane & 4;
+    double s = (h2 ? w[1] : w[0]) + __shfl_xor(h2 ? w[0] : w[1], 4);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 1);
+    // lane l now holds the total of value number 8*b5 + 4*b4 + 2*b3 + b2 of its own lane bits
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = __shfl(s, j << 2);
+}
+
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
@@ -134,8 +182,10 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
     double* xi = smem + 4 * H;                          // [peakLast + 1] intensity spectrum; later the suffix sums
     // region B is free once the spectrum is in xi: peak bins, then per-line masker counts (filled below)
     short* pkBin = reinterpret_cast<short*>(smem + 2 * H);              // [<= peakLast/2 + 1] peak bins, increasing
-    unsigned short* cntArr = reinterpret_cast<unsigned short*>(pkBin + ((S.peakLast / 2 + 3) & ~1));   // [M + 1]
+    unsigned short* cntArr = reinterpret_cast<unsigned short*>(pkBin + ((S.peakLast / 2 + 5) & ~3));   // [M + 1]
     unsigned short* nUpArr = cntArr + (M + 2);                           // [M + 1]
+    double* piHi = reinterpret_cast<double*>(nUpArr + (M + 2));          // [<= peakLast/2 + 2] prefix sums of the masker
+    double* piLo = piHi + (S.peakLast / 2 + 2);                          //   intensities, double-double (hi, lo)
 
     if (tid < kMaxBands) bandKey[tid] = 0ull;           // below every key; visible after the first barrier
     if (tid < 16) e2tab[tid] = kExp2Sixteenths[tid];
@@ -301,6 +351,33 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
                 if (m < nPeaks) sc[m] = loc[i] + higher;
             }
             if (lane == 0) sc[nPeaks] = 0.0;
+        } else if (wave == 1 % (kThreads / kWave)) {
+            // pi[m] = I_0 + ... + I_{m-1} in double-double: the in-band sum of a line is a DIFFERENCE of two
+            // prefix sums, and with ~106 bits the difference is exact to far below one ulp of the result even
+            // when a loud masker sits in the prefix (dynamic range of I within a frame < 2^50)
+            constexpr int kSeg = 8;
+            double hi = 0.0, lo = 0.0, locH[kSeg], locL[kSeg];
+#pragma unroll
+            for (int i = 0; i < kSeg; ++i) {
+                const int m = lane * kSeg + i;
+                locH[i] = hi; locL[i] = lo;                            // exclusive within the segment
+                dd_add(&hi, &lo, (m < nPeaks) ? mt[4 * m] : 0.0, 0.0);
+            }
+            double exH = 0.0, exL = 0.0, inH = hi, inL = lo;            // exclusive prefix scan of the segment totals
+#pragma unroll
+            for (int offl = 1; offl < kWave; offl <<= 1) {
+                const double oh = __shfl_up(inH, offl), ol = __shfl_up(inL, offl);
+                if (lane >= offl) { dd_add(&inH, &inL, oh, ol); dd_add(&exH, &exL, oh, ol); }
+            }
+#pragma unroll
+            for (int i = 0; i < kSeg; ++i) {
+                const int m = lane * kSeg + i;
+                if (m <= nPeaks) {
+                    double h = exH, l = exL;
+                    dd_add(&h, &l, locH[i], locL[i]);
+                    piHi[m] = h; piLo[m] = l;
+                }
+            }
         }
         // per-line masker counts: inclusive prefix sums of the two histograms the table build left
         // (cnt[k] = maskers with fl(z_k - z_m) >= -1/2, nUp[k] = maskers with fl(z_k - z_m) > 1/2)
@@ -391,14 +468,13 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
                             }
                         }
                         const double d = z - c;
-                        double p = 0.0;
+                        wave_sum_16(B, lane);                          // B[0..15]: totals over the wave, in every lane
+                        double top = B[kFarOrder];
 #pragma unroll
-                        for (int j = kFarOrder; j >= 0; --j) {
-                            double s = B[j];
+                        for (int offl = 32; offl > 0; offl >>= 1) top += __shfl_xor(top, offl);
+                        double p = top * kInvFactorial[kFarOrder];
 #pragma unroll
-                            for (int offl = 32; offl > 0; offl >>= 1) s += __shfl_xor(s, offl);
-                            p = fma(p, d, s * kInvFactorial[j]);
-                        }
+                        for (int j = kFarOrder - 1; j >= 0; --j) p = fma(p, d, B[j] * kInvFactorial[j]);
                         if (g == myGroup) tot += p;
                     }
                     mFirst = nFar;
@@ -419,7 +495,14 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
                 tot = fma(m < cnt ? I : 0.0, exp2_tab16(sl, u, e2tab), tot);
             }
             // no line of the chunk is above the band: every line that sees the masker is inside +-1/2 Bark
-            for (int m = mExp; m < mEnd; ++m) tot += (m < cnt) ? mt[4 * m] : 0.0;
+            if (cnt > mExp) {
+                // sum of I_m over [mExp, cnt) = pi[cnt] - pi[mExp], in double-double
+                const double ah = piHi[cnt], al = piLo[cnt], bh = piHi[mExp], bl = piLo[mExp];
+                const double d1 = ah - bh;
+                const double v = d1 - ah;
+                const double e = ((ah - (d1 - v)) - (bh + v)) + (al - bl);
+                tot += d1 + e;
+            }
             // maskers more than 1/2 Bark above the line: -27 dB/Bark for all of them
             const double t = fma(S.lowE[kc], sc[cnt], tot);
             const double thr = spl_db(t);                                    // psychoac.py:173
