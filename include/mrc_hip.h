@@ -157,6 +157,8 @@ int64_t mrc_pack_bound(const mrc_config* cfg, int a, int b, int n_channels, int 
 /* pacfileThem.py:586-613 (file header; num_samples is padded by the reference's inverted test). */
 int mrc_pac_header(const mrc_config* cfg, int n_channels, uint32_t num_samples, uint8_t* out, int64_t out_cap,
                    int64_t* out_len);
+/* Host threads used by mrc_pack_blocks / mrc_pack_joint_blocks (process-wide, default 1). */
+int mrc_pack_set_threads(int n_threads);
 /* What PACFile.WriteDataBlock appends per block (pacfileThem.py:652-790) for n_channels independent
  * channels: per channel `<L nBytes` + MSB-first payload {huffTable:4, blkswA, blkswB, overallScale, band
  * records}.  Arrays: overall_scale [n][nch], scale_factor / bit_alloc [n][nch][nBands], mantissa

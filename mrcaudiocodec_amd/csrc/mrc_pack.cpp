@@ -10,7 +10,10 @@
 // Table ids: sorted table names (percussive 0, silence 1, speech 2, tonal 3), 15 = raw; see DESIGN.md.
 #include "mrc_internal.hpp"
 
+#include <atomic>
 #include <cstring>
+#include <functional>
+#include <thread>
 
 namespace {
 
@@ -144,6 +147,22 @@ void write_band_records(BitWriter& w, const mrc_config& cfg, const int32_t* sf, 
     }
 }
 
+std::atomic<int> g_packThreads{1};
+
+// contiguous ranges over up to g_packThreads host threads (1 = run inline)
+template <class F> void parallel_for(int64_t n, F body) {
+    int nt = g_packThreads.load();
+    if (nt > n) nt = (int)n;
+    if (nt <= 1) { for (int64_t i = 0; i < n; ++i) body(i); return; }
+    std::vector<std::thread> pool;
+    pool.reserve((size_t)nt);
+    for (int t = 0; t < nt; ++t) {
+        const int64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        pool.emplace_back([lo, hi, &body] { for (int64_t i = lo; i < hi; ++i) body(i); });
+    }
+    for (auto& th : pool) th.join();
+}
+
 inline void put_u32le(uint8_t* p, uint32_t v) { p[0] = v & 255; p[1] = (v >> 8) & 255; p[2] = (v >> 16) & 255; p[3] = v >> 24; }
 
 bool shape_ok(const mrc_config* cfg, int a, int b) {
@@ -213,42 +232,62 @@ static int pack_blocks(const mrc_config* cfg, int64_t n, int nch, int a, int b, 
     const int half = (a + b) / 2;
     const int nScalePerBlock = joint ? 4 : nch;
     const uint32_t bitA = (uint32_t)(1 - a / cfg->n_mdct_lines), bitB = (uint32_t)(1 - b / cfg->n_mdct_lines);   // py2 int division
+    // Two passes so that blocks can be packed by several host threads (mrc_pack_set_threads): (1) table choice
+    // and chunk size of every channel chunk, (2) serial prefix sum of the sizes, (3) payloads at known offsets.
+    const int64_t nChunks = n * nch;
+    std::vector<ChannelPlan> plans((size_t)nChunks);
+    std::vector<int64_t> chunkBytes((size_t)nChunks);
+    parallel_for(nChunks, [&](int64_t c) {
+        const int ch = (int)(c % nch);
+        const ChannelPlan plan = plan_channel(bit_alloc + c * nb, mantissa + c * (int64_t)half, nLines, use_huffman);
+        int64_t bits = 4 + cfg->blksw_bits_a + cfg->blksw_bits_b + (int64_t)nb * (cfg->n_mant_size_bits + cfg->n_scale_bits) +
+                       plan.mantBits;
+        if (joint) { if (ch == 0) bits += nb + 4 * cfg->n_scale_bits; }           // pacfileThem.py:826-833
+        else bits += cfg->n_scale_bits;                                           // pacfileThem.py:655
+        plans[(size_t)c] = plan;
+        chunkBytes[(size_t)c] = (bits + 7) / 8;                                   // pacfileThem.py:706-707
+        if (huff_table) huff_table[c] = plan.table;
+        if (bits_saved) bits_saved[c] = plan.bitsSaved;
+    });
+    std::vector<int64_t> chunkPos((size_t)nChunks + 1);
     int64_t pos = 0;
-    for (int64_t i = 0; i < n; ++i) {
-        block_offset[i] = pos;
-        for (int ch = 0; ch < nch; ++ch) {
-            const int32_t* sf = scale_factor + (i * nch + ch) * nb;
-            const int32_t* ba = bit_alloc + (i * nch + ch) * nb;
-            const int32_t* dense = mantissa + (i * nch + ch) * (int64_t)half;
-            const ChannelPlan plan = plan_channel(ba, dense, nLines, use_huffman);
-            if (huff_table) huff_table[i * nch + ch] = plan.table;
-            if (bits_saved) bits_saved[i * nch + ch] = plan.bitsSaved;
-            int64_t bits = 4 + cfg->blksw_bits_a + cfg->blksw_bits_b + (int64_t)nb * (cfg->n_mant_size_bits + cfg->n_scale_bits) +
-                           plan.mantBits;
-            if (joint) { if (ch == 0) bits += nb + 4 * cfg->n_scale_bits; }       // pacfileThem.py:826-833
-            else bits += cfg->n_scale_bits;                                       // pacfileThem.py:655
-            const int64_t nBytes = (bits + 7) / 8;                                // pacfileThem.py:706-707
-            if (pos + 4 + nBytes > out_cap) return MRC_ERR_NOMEM;
-            put_u32le(out + pos, (uint32_t)nBytes);
-            BitWriter w(out + pos + 4);
-            w.put((uint32_t)plan.table, 4);
-            w.put(bitA, cfg->blksw_bits_a);
-            w.put(bitB, cfg->blksw_bits_b);
-            if (joint) {
-                if (ch == 0) {
-                    for (int s = 0; s < 4; ++s) w.put((uint32_t)overall_scale[i * 4 + s], cfg->n_scale_bits);   // L,R,M,S
-                    for (int k = 0; k < nb; ++k) w.put((uint32_t)ms_switch[i * nb + k], 1);
-                }
-            } else {
-                w.put((uint32_t)overall_scale[i * nScalePerBlock + ch], cfg->n_scale_bits);
-            }
-            write_band_records(w, *cfg, sf, ba, dense, nLines, plan.table);
-            w.flush();
-            if (w.p - (out + pos + 4) != nBytes) return MRC_ERR_INVALID;          // size law and writer disagree: bug
-            pos += 4 + nBytes;
-        }
+    for (int64_t c = 0; c < nChunks; ++c) {
+        if (c % nch == 0) block_offset[c / nch] = pos;
+        chunkPos[(size_t)c] = pos;
+        pos += 4 + chunkBytes[(size_t)c];
     }
+    if (pos > out_cap) return MRC_ERR_NOMEM;
+    std::atomic<int> bad{0};
+    parallel_for(nChunks, [&](int64_t c) {
+        const int64_t i = c / nch;
+        const int ch = (int)(c % nch);
+        const ChannelPlan& plan = plans[(size_t)c];
+        uint8_t* dst = out + chunkPos[(size_t)c];
+        put_u32le(dst, (uint32_t)chunkBytes[(size_t)c]);
+        BitWriter w(dst + 4);
+        w.put((uint32_t)plan.table, 4);
+        w.put(bitA, cfg->blksw_bits_a);
+        w.put(bitB, cfg->blksw_bits_b);
+        if (joint) {
+            if (ch == 0) {
+                for (int s4 = 0; s4 < 4; ++s4) w.put((uint32_t)overall_scale[i * 4 + s4], cfg->n_scale_bits);   // L,R,M,S
+                for (int k = 0; k < nb; ++k) w.put((uint32_t)ms_switch[i * nb + k], 1);
+            }
+        } else {
+            w.put((uint32_t)overall_scale[i * nScalePerBlock + ch], cfg->n_scale_bits);
+        }
+        write_band_records(w, *cfg, scale_factor + c * nb, bit_alloc + c * nb, mantissa + c * (int64_t)half, nLines, plan.table);
+        w.flush();
+        if (w.p - (dst + 4) != chunkBytes[(size_t)c]) bad.store(1);              // size law and writer disagree: bug
+    });
+    if (bad.load()) return MRC_ERR_INVALID;
     block_offset[n] = pos;
+    return MRC_OK;
+}
+
+int mrc_pack_set_threads(int n_threads) {
+    if (n_threads < 1 || n_threads > 1024) return MRC_ERR_INVALID;
+    g_packThreads.store(n_threads);
     return MRC_OK;
 }
 

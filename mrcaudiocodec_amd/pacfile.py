@@ -33,6 +33,11 @@ def make_config(sample_rate=48000, n_mdct_lines=1024, n_short=128, n_scale_bits=
     return cfg
 
 
+def set_threads(n):
+    """Host threads the C++ packer uses for a batch of blocks (process-wide, default 1)."""
+    _check(lib.mrc_pack_set_threads(int(n)), "mrc_pack_set_threads")
+
+
 def _check(rc, what):
     if rc != 0:
         raise MrcError("%s failed (%d)" % (what, rc))

@@ -312,6 +312,22 @@ def test_pac_bytes_stereo_stream(h, huff):
     assert ppac.encode_stereo_stream(h, t2, shapes2, use_huffman=huff) == opac.encode_stereo_stream(t2, shapes2, huffman=huff)
 
 
+def test_device_offsets_block_switched_stream(h):
+    # device API with an explicit offsets[] array per block shape (how a block-switched stream is batched)
+    torch = pytest.importorskip("torch")
+    from mrcaudiocodec_amd import synth
+    from mrcaudiocodec_amd.batch import StreamEncoder
+    x, shapes = synth.c4_transients(30)
+    enc = StreamEncoder(handle=h)
+    dev = torch.from_numpy(x).to("cuda:0")
+    for (a, b) in SHAPES:
+        offs = [o for (o, aa, bb) in shapes if (aa, bb) == (a, b)]
+        out = enc.encode(a, b, dev, None, len(offs), 0, torch.tensor(offs, dtype=torch.int64, device="cuda:0"))
+        ref = fast.encode_mono_batch(np.stack([x[o:o + a + b] for o in offs]), a, b)
+        for k in _int_keys(False):
+            assert np.array_equal(out[k].cpu().numpy().reshape(np.asarray(ref[k]).shape), ref[k]), (a, b, k)
+
+
 # ------------------------------------------------------------------ other codec parameters
 def test_training_script_parameters_44k():
     # huffman_training_script.py:39-45: nScaleBits 3, nMantSizeBits 5, 2.27 bits/sample -- at 44.1 kHz the

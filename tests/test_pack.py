@@ -73,6 +73,22 @@ def test_pack_joint(huff):
         assert data[offs[i]:offs[i + 1]].tobytes() == want, i
 
 
+def test_pack_threads_give_identical_bytes():
+    s = synth.c3_stereo(40)
+    bl, br = np.array(fast.blocks_from_stream(s[0], 1024)), np.array(fast.blocks_from_stream(s[1], 1024))
+    r = fast.encode_joint_batch(bl, br, 1024, 1024)
+    cfg = ppac.make_config()
+    args = (cfg, 1024, 1024, r["overall_scale"], r["ms_switch"], r["scale_factor"], r["bit_alloc"], r["mantissa"])
+    one = ppac.pack_joint_blocks(*args)
+    try:
+        ppac.set_threads(5)
+        many = ppac.pack_joint_blocks(*args)
+    finally:
+        ppac.set_threads(1)
+    assert one[0].tobytes() == many[0].tobytes() and np.array_equal(one[1], many[1])
+    assert np.array_equal(one[2], many[2]) and np.array_equal(one[3], many[3])
+
+
 def test_pack_escape_and_buffer_checks():
     # hand-made block: values outside every table and the escape value itself (priced without its raw bits,
     # written with them: codecThem.py:169-172 vs 194-200)
