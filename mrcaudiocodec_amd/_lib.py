@@ -72,6 +72,8 @@ def _load():
         "mrc_bitalloc": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, _i32p, _f64p, _f64p, _i32p, _i32p]),
         "mrc_scale_factor": (C.c_int, [H, C.c_int64, C.c_int, _f64p, _i32p, _i32p]),
         "mrc_mantissa": (C.c_int, [H, C.c_int64, C.c_int, _f64p, _i32p, _i32p, _i32p]),
+        "mrc_transient_peaks": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, _f64p, _f64p, _f64p]),
+        "mrc_stereo_masking_factor": (C.c_int, [H, C.c_int64, _f64p, _f64p, _f64p, _f64p, _f64p]),
         "mrc_ms_switch": (C.c_int, [H, C.c_int64, C.c_int, _i32p, _f64p, _f64p, _i32p]),
         "mrc_dev_mdct": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                    C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -265,6 +267,28 @@ class Handle:
         self._check(lib.mrc_mantissa(self._h, x.size, int(n_scale_bits), _p(x, _f64p), _p(sc, _i32p), _p(mb, _i32p),
                                      _p(out, _i32p)))
         return out
+
+    def transient_peaks(self, streams, sos):
+        """streams [nCh][(nHops+1)*hop] -> peaks [nHops][nCh][hop/nShort + 1] (sub-block peaks, then the hop's peak)."""
+        x = _f64(np.atleast_2d(streams))
+        sos = _f64(sos)
+        hop, n_short = self.cfg.n_mdct_lines, self.cfg.n_short
+        n_hops = x.shape[1] // hop - 1
+        if x.shape[1] != (n_hops + 1) * hop or sos.ndim != 2 or sos.shape[1] != 6:
+            raise ValueError("streams must be [nCh][(nHops+1)*hop], sos [nSections][6]")
+        out = np.empty((max(n_hops, 0), x.shape[0], hop // n_short + 1), np.float64)
+        self._check(lib.mrc_transient_peaks(self._h, n_hops, x.shape[0], sos.shape[0], _p(sos, _f64p), _p(x, _f64p),
+                                            _p(out, _f64p)))
+        return out
+
+    def stereo_masking_factor(self, mid_thresh, side_thresh, z):
+        m, s_, zz = _f64(mid_thresh), _f64(side_thresh), _f64(z)
+        if not (m.shape == s_.shape == zz.shape):
+            raise ValueError("mid, side and z must have the same shape")
+        om, os_ = np.empty_like(m), np.empty_like(m)
+        self._check(lib.mrc_stereo_masking_factor(self._h, m.size, _p(m, _f64p), _p(s_, _f64p), _p(zz, _f64p),
+                                                  _p(om, _f64p), _p(os_, _f64p)))
+        return om, os_
 
     def ms_switch(self, lines_left, lines_right, n_lines):
         L, R = _f64(np.atleast_2d(lines_left)), _f64(np.atleast_2d(lines_right))

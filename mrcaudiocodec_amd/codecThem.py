@@ -12,7 +12,8 @@ Kept from the reference:
   Encode / EncodeNoHuff / JointEncode            codecThem.py:205-278
   calculateHuffmanGain(mantissa, bitAlloc, cp)   codecThem.py:136-203  (host side, as BASELINE.json's north_star says)
   L1 names re-exported by codecThem.py:14-21:    TransitionWindow, KBDWindow, MDCT, CalcSMRs,
-      getMaskedThreshold, BitAlloc, ScaleFactor, vMantissa, MSSwitchSFBands, OverallSMRs -- each runs on the GPU.
+      getMaskedThreshold, BitAlloc, ScaleFactor, vMantissa, MSSwitchSFBands, StereoMaskingFactor, OverallSMRs --
+      each runs on the GPU.
 codingParams is the reference's attribute bag (audiofile.py:51-53): read a, b, nMDCTLines, nScaleBits,
 nMantSizeBits, targetBitsPerSample, sampleRate, sfBands, blkswBitA/B, nChannels, bitReservoir;
 written bitReservoir (codecThem.py:224,274,332,503).
@@ -240,6 +241,12 @@ def vMantissa(aNumVec, scale, nScaleBits=3, nMantBits=5):
 def MSSwitchSFBands(mdct_left, mdct_right, sfBands):
     """ms_stereo.py:5-27."""
     return [int(v) for v in _default_handle().ms_switch(mdct_left, mdct_right, np.asarray(sfBands.nLines))[0]]
+
+
+def StereoMaskingFactor(midThresh, sideThresh, sfBands, zVec):
+    """ms_stereo.py:53-67 -> [final_midThresh, final_sideThresh] (the encoder never uses the result: psychoac.py:205-210)."""
+    om, os_ = _default_handle().stereo_masking_factor(midThresh, sideThresh, zVec)
+    return [om, os_]
 
 
 def OverallSMRs(SMR_l, SMR_r, SMR_m, SMR_s, sfBands, ms_switch):

@@ -489,6 +489,47 @@ int mrc_mantissa(mrc_handle* h, int64_t n, int n_scale_bits, const double* x, co
     return MRC_OK;
 }
 
+int mrc_transient_peaks(mrc_handle* h, int64_t n_hops, int n_channels, int n_sections, const double* sos,
+                        const double* streams, double* peaks) {
+    if (!h || !sos || !streams || !peaks || n_hops < 0 || n_channels < 1 || n_sections < 1 || n_sections > 16)
+        return fail(h, MRC_ERR_INVALID, "mrc_transient_peaks: bad argument (1 <= n_sections <= 16)");
+    if (n_hops == 0) return MRC_OK;
+    const int hop = h->cfg.n_mdct_lines, nShort = h->cfg.n_short;
+    if (hop % nShort != 0) return fail(h, MRC_ERR_INVALID, "mrc_transient_peaks: n_mdct_lines must be a multiple of n_short");
+    const int64_t chStride = (n_hops + 1) * (int64_t)hop;
+    MRC_HIP(h, hipSetDevice(h->device));
+    Staged s{h, h->stream};
+    MRC_TRY(s.up(h->inL, streams, (size_t)n_channels * chStride * sizeof(double)));
+    MRC_TRY(s.up(h->inAux3, sos, (size_t)n_sections * 6 * sizeof(double)));
+    const size_t outBytes = (size_t)n_hops * n_channels * (hop / nShort + 1) * sizeof(double);
+    MRC_HIP(h, h->outG.reserve(outBytes));
+    MRC_HIP(h, launch_transient_peaks(n_hops, n_channels, hop, nShort, n_sections, h->inAux3.as<double>(),
+                                      h->inL.as<double>(), chStride, h->outG.as<double>(), h->stream));
+    MRC_TRY(s.down(peaks, h->outG, outBytes));
+    MRC_HIP(h, hipStreamSynchronize(h->stream));
+    return MRC_OK;
+}
+
+int mrc_stereo_masking_factor(mrc_handle* h, int64_t n, const double* mid_thresh, const double* side_thresh,
+                              const double* z, double* out_mid, double* out_side) {
+    if (!h || !mid_thresh || !side_thresh || !z || !out_mid || !out_side || n < 0)
+        return fail(h, MRC_ERR_INVALID, "mrc_stereo_masking_factor: bad argument");
+    if (n == 0) return MRC_OK;
+    MRC_HIP(h, hipSetDevice(h->device));
+    Staged s{h, h->stream};
+    const size_t bytes = (size_t)n * sizeof(double);
+    MRC_TRY(s.up(h->inL, mid_thresh, bytes));
+    MRC_TRY(s.up(h->inR, side_thresh, bytes));
+    MRC_TRY(s.up(h->inAux3, z, bytes));
+    MRC_HIP(h, h->outG.reserve(bytes)); MRC_HIP(h, h->outE.reserve(bytes));
+    MRC_HIP(h, launch_stereo_masking(n, h->inL.as<double>(), h->inR.as<double>(), h->inAux3.as<double>(),
+                                     h->outG.as<double>(), h->outE.as<double>(), h->stream));
+    MRC_TRY(s.down(out_mid, h->outG, bytes));
+    MRC_TRY(s.down(out_side, h->outE, bytes));
+    MRC_HIP(h, hipStreamSynchronize(h->stream));
+    return MRC_OK;
+}
+
 int mrc_ms_switch(mrc_handle* h, int64_t n_blocks, int n_bands, const int32_t* n_lines, const double* lines_left,
                   const double* lines_right, int32_t* ms_switch) {
     if (!h || !n_lines || !lines_left || !lines_right || !ms_switch || n_blocks < 0 || n_bands < 1 ||

@@ -104,6 +104,63 @@ __global__ void unscale_kernel(int halfN, int64_t total, const double* __restric
     if (i < total) lines[i] = ldexp(scaled[i], -oscale[i / halfN]);
 }
 
+// pacfileThem.py:1025-1056 (TransientDetector), the numeric part: every hop is high-pass filtered from a ZERO
+// state by a cascade of second-order sections (scipy.signal.sosfilt's direct-form-II-transposed recurrence,
+// same operation order) and the peak |y| of each short sub-block plus the peak of the whole hop are kept.
+// One thread per (hop, channel): the recurrence is serial in time, hops are independent.
+constexpr int kMaxSections = 16;
+__global__ void transient_peaks_kernel(int64_t nHops, int nCh, int hop, int nShort, int nSec,
+                                       const double* __restrict__ sos, const double* __restrict__ streams,
+                                       int64_t chStride, double* __restrict__ peaks) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nHops * nCh) return;
+    const int64_t h = t / nCh;
+    const int ch = (int)(t % nCh);
+    const double* x = streams + ch * chStride + (h + 1) * hop;          // the stream starts with the prior hop
+    const int nSub = hop / nShort;
+    double* out = peaks + t * (nSub + 1);
+    double z0[kMaxSections], z1[kMaxSections];
+#pragma unroll
+    for (int s = 0; s < kMaxSections; ++s) { z0[s] = 0.0; z1[s] = 0.0; }
+    double all = 0.0;
+    for (int sb = 0; sb < nSub; ++sb) {
+        double pk = 0.0;
+        for (int n = 0; n < nShort; ++n) {
+            double cur = x[sb * nShort + n];
+#pragma unroll
+            for (int s = 0; s < kMaxSections; ++s) {
+                if (s < nSec) {
+                    const double b0 = sos[6 * s], b1 = sos[6 * s + 1], b2 = sos[6 * s + 2];
+                    const double a1 = sos[6 * s + 4], a2 = sos[6 * s + 5];
+                    const double y = b0 * cur + z0[s];
+                    z0[s] = (b1 * cur - a1 * y) + z1[s];
+                    z1[s] = b2 * cur - a2 * y;
+                    cur = y;
+                }
+            }
+            pk = fmax(pk, fabs(cur));
+        }
+        out[sb] = pk;
+        all = fmax(all, pk);
+    }
+    out[nSub] = all;
+}
+
+// ms_stereo.py:53-67: masking-level-difference factor MLD = 10^(1.25 (1 - cos(pi min(z,15.5)/15.5) - 2.5)) and
+// the cross-limited mid / side thresholds.  (The encoder's use of it is dead -- psychoac.py:205-210 -- the
+// kernel exists so that the drop-in module keeps the reference's symbol.)
+__global__ void stereo_masking_kernel(int64_t n, const double* __restrict__ mid, const double* __restrict__ side,
+                                      const double* __restrict__ z, double* __restrict__ outMid,
+                                      double* __restrict__ outSide) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double zc = fmin(z[i], 15.5);
+    const double mld = pow(10.0, 1.25 * (1 - cos((M_PI / 15.5) * zc) - 2.5));
+    const double m = mid[i], s = side[i];
+    outMid[i] = fmax(m, fmin(s, mld * s));
+    outSide[i] = fmax(s, fmin(m, mld * m));
+}
+
 __global__ __launch_bounds__(kWave) void ms_switch_kernel(int nBands, int nTotal, const int* __restrict__ bandLo,
                                                           const int* __restrict__ bandN, const double* __restrict__ L,
                                                           const double* __restrict__ R, int* __restrict__ out) {
@@ -159,6 +216,23 @@ hipError_t launch_mantissa(int64_t n, int nScaleBits, const double* x, const int
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(mantissa_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, nScaleBits, x, scale,
                        nMantBits, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_transient_peaks(int64_t nHops, int nCh, int hop, int nShort, int nSec, const double* sos,
+                                  const double* streams, int64_t chStride, double* peaks, hipStream_t st) {
+    const int64_t n = nHops * nCh;
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(transient_peaks_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, nHops, nCh, hop, nShort,
+                       nSec, sos, streams, chStride, peaks);
+    return hipGetLastError();
+}
+
+hipError_t launch_stereo_masking(int64_t n, const double* mid, const double* side, const double* z, double* outMid,
+                                 double* outSide, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(stereo_masking_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, mid, side, z,
+                       outMid, outSide);
     return hipGetLastError();
 }
 

@@ -71,6 +71,17 @@ def test_ms_switch_golden(h, golden_dir):
         assert np.array_equal(got, g["switch_%d" % k]), k
 
 
+def test_stereo_masking_factor_golden(h, golden_dir):
+    # ms_stereo.py:53-67 (its use in the encoder is dead, psychoac.py:205-210; kept for the drop-in's symbol).
+    # Golden outputs come from the reference's own module; pow/cos differ from libm in the last ulps.
+    import mrcaudiocodec_amd.codecThem as codec
+    g = _load(golden_dir, "ms_stereo.npz")
+    for k in range(int(g["n"])):
+        got = codec.StereoMaskingFactor(g["midT_%d" % k], g["sideT_%d" % k], None, g["z_%d" % k])
+        np.testing.assert_allclose(got[0], g["smf0_%d" % k], rtol=1e-14, atol=0)
+        np.testing.assert_allclose(got[1], g["smf1_%d" % k], rtol=1e-14, atol=0)
+
+
 # ------------------------------------------------------------------ stages vs oracle
 def _noise_blocks(a, b, n, seed=99, sigma=0.1):
     from mrcaudiocodec_amd import synth
