@@ -8,7 +8,8 @@ with the dense arrays the GPU path returns.  Mirrors the encode half of the refe
     PACFile.JointWriteDataBlock  pacfileThem.py:793-972   -> pack_joint_blocks()
     the CLI's encode loop + Close pacfileThem.py:1159-1214, 973-984 -> encode_stereo_stream()
 
-Block shapes are an input (the transient detector is not part of this build).
+Block shapes are an input here; mrcaudiocodec_amd/transient.py derives them from the audio like the reference's
+transient detector, and mrcaudiocodec_amd/cli.py strings WAV ingest, detector and this writer together.
 """
 import ctypes as C
 
@@ -97,7 +98,7 @@ def pack_joint_blocks(cfg, a, b, overall_scale, ms_switch, scale_factor, bit_all
     return _run_pack(lib.mrc_pack_joint_blocks, cfg, n, 2, a, b, 1, args)
 
 
-def encode_stereo_stream(handle, stream, shapes, use_huffman=True):
+def encode_stereo_stream(handle, stream, shapes, use_huffman=True, num_samples=None):
     """The encode half of the reference CLI for a stereo stream [2][samples] that starts with the zero
     prior hop and a given block-shape sequence [(offset, a, b)]: header, one joint block per shape with the
     bit reservoir chained through the Huffman savings (codecThem.py:274,503), then Close()'s flush block
@@ -110,7 +111,7 @@ def encode_stereo_stream(handle, stream, shapes, use_huffman=True):
     if shapes[-1][2] != L:
         raise ValueError("the stream must end with a long block (the reference's Close() assumes it)")
     stream = np.asarray(stream, dtype=np.float64)
-    out = [header(cfg, 2, sum(b for (_, _, b) in shapes))]
+    out = [header(cfg, 2, sum(b for (_, _, b) in shapes) if num_samples is None else num_samples)]   # the CLI writes the WAV's count
     reservoir = 0
     for (off, a, b) in shapes:
         r = handle.encode_joint(stream[0, off:off + a + b][None, :], stream[1, off:off + a + b][None, :], a, b, [reservoir])

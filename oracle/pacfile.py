@@ -162,7 +162,7 @@ def pack_joint_block(scaleFactor, bitAlloc, mantissa, overallScaleFactor, ms_swi
     return out
 
 
-def encode_stereo_stream(stream, shapes, cp=None, huffman=True):
+def encode_stereo_stream(stream, shapes, cp=None, huffman=True, num_samples=None):
     """The encode half of the reference CLI (pacfileThem.py:1105-1214 + Close 973-984) for a stereo
     stream that starts with the zero prior hop and a GIVEN sequence of block shapes [(offset, a, b)]
     (the transient detector is out of scope): header, one JointWriteDataBlock per shape with the bit
@@ -172,7 +172,7 @@ def encode_stereo_stream(stream, shapes, cp=None, huffman=True):
     if shapes[-1][2] != cp.nMDCTLines:
         raise ValueError("the stream must end with a long block: the reference's Close() pushes nMDCTLines zeros "
                          "through WriteDataBlock without updating b (pacfileThem.py:973-984) and fails otherwise")
-    n_new = sum(b for (_, _, b) in shapes)
+    n_new = sum(b for (_, _, b) in shapes) if num_samples is None else num_samples   # the CLI writes the WAV's count
     out = file_header(cp, n_new)
     for (off, a, b) in shapes:
         cp.a, cp.b = a, b
@@ -193,3 +193,20 @@ def encode_stereo_stream(stream, shapes, cp=None, huffman=True):
     r = codec.Encode(blk, cp) if huffman else codec.EncodeNoHuff(blk, cp)
     out += pack_block(r[0], r[1], r[2], r[3], r[4], cp)
     return out
+
+
+def encode_wav(path, huffman=True):
+    """The encode direction of `python pacfileThem.py in.wav` (pacfileThem.py:1084-1226) for a stereo 16-bit
+    WAV: ingest (pcmfile), transient detection with one hop of look-ahead, joint blocks, Close().  Returns the
+    .pac bytes.  As in the reference, the LAST hop of the file is analysed but never encoded."""
+    from . import pcmfile, transient
+    sampleRate, nChannels, numSamples, hops = pcmfile.read_wav(path)
+    if nChannels != 2:
+        raise ValueError("the reference CLI only works for stereo input (codecThem.py:264-265)")
+    cp = codec.default_params(sampleRate=sampleRate, nChannels=2)
+    stream = np.concatenate([np.zeros((2, cp.nMDCTLines)), hops], axis=1)
+    shapes = transient.block_shapes(stream, cp)
+    if not shapes:
+        raise ValueError("file too short: the reference writes no block for fewer than two hops")
+    cp.bitReservoir = 0
+    return encode_stereo_stream(stream, shapes, cp, huffman, num_samples=numSamples)

@@ -58,3 +58,45 @@ def test_transient_peaks_kernel_and_shapes_on_gpu():
         assert m == otr.block_shapes(s[:1], ocodec.default_params(nChannels=1), sos)
     finally:
         h.close()
+
+
+# ------------------------------------------------------------------ WAV ingest + the encode CLI (next row f-3)
+def _write_wav(path, pcm_lr, rate=48000):
+    import wave
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(rate)
+        w.writeframes(np.ascontiguousarray(pcm_lr.T.astype("<i2")).tobytes())
+
+
+def _test_pcm(n):
+    rng = np.random.default_rng(11)
+    t = np.arange(n)
+    left = 6000 * np.sin(2 * np.pi * 440 * t / 48000) + rng.normal(0, 300, n)
+    left[5000:5100] += rng.normal(0, 15000, 100)                   # a click -> short blocks
+    right = 0.7 * left + rng.normal(0, 200, n)
+    pcm = np.clip(np.rint(np.stack([left, right])), -32768, 32767)
+    pcm[0, 17] = -32768                                            # the code the reference maps to 0.0
+    return pcm
+
+
+def test_wav_ingest_matches_oracle(tmp_path):
+    from mrcaudiocodec_amd import cli
+    from oracle import pcmfile as opcm
+    pcm = _test_pcm(7 * 1024 + 333)                                # partial last hop -> zero padded
+    _write_wav(tmp_path / "a.wav", pcm)
+    r1 = cli.read_wav(str(tmp_path / "a.wav"))
+    r2 = opcm.read_wav(str(tmp_path / "a.wav"))
+    assert r1[:3] == r2[:3] == (48000, 2, 7 * 1024 + 333)
+    assert np.array_equal(r1[3], r2[3]) and r1[3].shape == (2, 8 * 1024) and r1[3][0, 17] == 0.0
+
+
+@pytest.mark.gpu
+def test_cli_encode_wav_bytes_equal_oracle(tmp_path):
+    from mrcaudiocodec_amd import cli
+    from oracle import pacfile as opac
+    pcm = _test_pcm(9 * 1024 + 100)
+    _write_wav(tmp_path / "b.wav", pcm)
+    got = cli.encode_wav(str(tmp_path / "b.wav"), str(tmp_path / "b.pac"))
+    want = opac.encode_wav(str(tmp_path / "b.wav"))
+    assert got == want and (tmp_path / "b.pac").read_bytes() == want
+    assert cli.encode_wav(str(tmp_path / "b.wav"), use_huffman=False) == opac.encode_wav(str(tmp_path / "b.wav"), huffman=False)
