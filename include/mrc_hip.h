@@ -192,6 +192,17 @@ int mrc_pack_joint_blocks(const mrc_config* cfg, int64_t n_blocks, int a, int b,
                           const int32_t* bit_alloc, const int32_t* mantissa, uint8_t* out, int64_t out_cap,
                           int64_t* block_offset, int32_t* huff_table, int32_t* bits_saved);
 
+/* Huffman table PRICING on the device (codecThem.py:136-180,202): per (frame, stream) the id of the cheapest
+ * table (15 = raw) and bits_saved.  Lets a chained multi-stream encode carry the reservoir from block to block
+ * without leaving the GPU; the bytes are produced later by mrc_pack_*.  bit_alloc [n][n_streams][nBands],
+ * mantissa [n][n_streams][N/2] dense.  Device form: reservoir_next[f] (may be NULL) = reservoir_out[f] + sum
+ * over the frame's streams of bits_saved -- the reservoir the stream's next block starts from (codecThem.py:274). */
+int mrc_huffman_gain(mrc_handle* h, int64_t n_blocks, int a, int b, int n_streams, const int32_t* bit_alloc,
+                     const int32_t* mantissa, int32_t* huff_table, int32_t* bits_saved);
+int mrc_dev_huffman_gain(mrc_handle* h, int a, int b, int64_t n_frames, int n_streams, const int32_t* bit_alloc,
+                         const int32_t* mantissa, const int32_t* reservoir_out, int32_t* huff_table,
+                         int32_t* bits_saved, int32_t* reservoir_next, void* stream);
+
 /* Per-stage device time of the most recent mrc_dev_encode / stage call when timing is enabled
  * (hipEvents on the launch stream; the call then synchronises).  ms[0..2] = mdct, smr, alloc+quant. */
 int mrc_set_timing(mrc_handle* h, int enabled);

@@ -82,6 +82,8 @@ def _load():
         "mrc_dev_alloc_quant": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_int] + [C.c_void_p] * 10),
         "mrc_dev_encode": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64] +
                            [C.c_void_p] * 10),
+        "mrc_huffman_gain": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p]),
+        "mrc_dev_huffman_gain": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_int] + [C.c_void_p] * 7),
         "mrc_band_table": (C.c_int, [C.POINTER(MrcConfig), C.c_int, C.c_int, _i32p, _i32p]),
         "mrc_pack_bound": (C.c_int64, [C.POINTER(MrcConfig), C.c_int, C.c_int, C.c_int, C.c_int]),
         "mrc_pac_header": (C.c_int, [C.POINTER(MrcConfig), C.c_int, C.c_uint32, _u8p, C.c_int64, _i64p]),
@@ -267,6 +269,21 @@ class Handle:
         self._check(lib.mrc_mantissa(self._h, x.size, int(n_scale_bits), _p(x, _f64p), _p(sc, _i32p), _p(mb, _i32p),
                                      _p(out, _i32p)))
         return out
+
+    def huffman_gain(self, bit_alloc, mantissa, a, b):
+        """bit_alloc [n][nStreams][nBands], mantissa [n][nStreams][N/2] dense -> (table id [n][nStreams], bits_saved)."""
+        ba, m = _i32(bit_alloc), _i32(mantissa)
+        n, ns = ba.shape[0], ba.shape[1]
+        table = np.empty((n, ns), np.int32)
+        saved = np.empty((n, ns), np.int32)
+        self._check(lib.mrc_huffman_gain(self._h, n, int(a), int(b), ns, _p(ba, _i32p), _p(m, _i32p), _p(table, _i32p),
+                                         _p(saved, _i32p)))
+        return table, saved
+
+    def dev_huffman_gain(self, a, b, n_frames, n_streams, bit_alloc, mantissa, reservoir_out, huff_table, bits_saved,
+                         reservoir_next=None, stream=None):
+        self._check(lib.mrc_dev_huffman_gain(self._h, a, b, n_frames, n_streams, bit_alloc, mantissa, reservoir_out,
+                                             huff_table, bits_saved, reservoir_next, stream))
 
     def transient_peaks(self, streams, sos):
         """streams [nCh][(nHops+1)*hop] -> peaks [nHops][nCh][hop/nShort + 1] (sub-block peaks, then the hop's peak)."""

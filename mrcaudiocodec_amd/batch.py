@@ -24,23 +24,26 @@ class StreamEncoder:
         self.device = torch.device("cuda", self.h.cfg.device_id)
         self._out = {}
 
+    def _alloc(self, n, joint, nb, half):
+        nsig, nstream = (4, 2) if joint else (1, 1)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        return dict(overall_scale=torch.empty((n, nsig), **i32),
+                    ms_switch=torch.empty((n, nb), **i32) if joint else None,
+                    bit_alloc=torch.empty((n, nstream, nb), **i32),
+                    scale_factor=torch.empty((n, nstream, nb), **i32),
+                    mantissa=torch.empty((n, nstream, half), **i32),
+                    reservoir_out=torch.empty((n,), **i32))
+
     def _outputs(self, n, joint, nb, half):
         key = (n, joint, nb, half)
         if key not in self._out:
-            nsig, nstream = (4, 2) if joint else (1, 1)
-            i32 = dict(dtype=torch.int32, device=self.device)
-            self._out = {key: dict(
-                overall_scale=torch.empty((n, nsig), **i32),
-                ms_switch=torch.empty((n, nb), **i32) if joint else None,
-                bit_alloc=torch.empty((n, nstream, nb), **i32),
-                scale_factor=torch.empty((n, nstream, nb), **i32),
-                mantissa=torch.empty((n, nstream, half), **i32),
-                reservoir_out=torch.empty((n,), **i32))}
+            self._out = {key: self._alloc(n, joint, nb, half)}
         return self._out[key]
 
-    def encode(self, a, b, left, right, n_frames, frame_stride, offsets=None, reservoir_in=None, lines_out=None):
+    def encode(self, a, b, left, right, n_frames, frame_stride, offsets=None, reservoir_in=None, lines_out=None,
+               fresh=False):
         """Encode n_frames blocks of shape (a,b) read from device tensor(s) `left` (and `right` for joint stereo).
-        Returns a dict of device tensors (reused between calls of the same size)."""
+        Returns a dict of device tensors (reused between calls of the same size unless fresh=True)."""
         for t in (left, right, offsets, reservoir_in, lines_out):
             if t is not None and (not t.is_cuda or not t.is_contiguous()):
                 raise ValueError("device-contiguous tensors expected")
@@ -50,7 +53,7 @@ class StreamEncoder:
         if n_frames > 0 and (left.numel() < last or (right is not None and right.numel() < last)):
             raise ValueError("stream too short for %d frames" % n_frames)
         nb = len(self.h.bands(a, b))
-        out = self._outputs(n_frames, right is not None, nb, (a + b) // 2)
+        out = (self._alloc if fresh else self._outputs)(n_frames, right is not None, nb, (a + b) // 2)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         self.h.dev_encode(a, b, n_frames, _ptr(left), _ptr(right), frame_stride, _ptr(offsets), _ptr(reservoir_in),
                           _ptr(out["overall_scale"]), _ptr(out["ms_switch"]), _ptr(out["bit_alloc"]),
@@ -62,3 +65,46 @@ class StreamEncoder:
         """All-long-block stream (a = b = nMDCTLines), hop-overlapped layout."""
         L = self.h.cfg.n_mdct_lines
         return self.encode(L, L, left, right, n_frames, L, None, reservoir_in)
+
+    def huffman_gain(self, a, b, out, use_huffman=True):
+        """Prices the Huffman tables for the blocks in `out` (a dict from encode) on the device and returns
+        (huff_table [n][nStreams], bits_saved [n][nStreams], reservoir_next [n]) -- codecThem.py:136-203,224,274."""
+        n, ns = out["bit_alloc"].shape[0], out["bit_alloc"].shape[1]
+        i32 = dict(dtype=torch.int32, device=self.device)
+        if not use_huffman:                                     # EncodeNoHuff: raw mantissas, nothing saved
+            return (torch.full((n, ns), 15, **i32), torch.zeros((n, ns), **i32), out["reservoir_out"].clone())
+        table, saved, nxt = torch.empty((n, ns), **i32), torch.empty((n, ns), **i32), torch.empty((n,), **i32)
+        self.h.dev_huffman_gain(a, b, n, ns, _ptr(out["bit_alloc"]), _ptr(out["mantissa"]), _ptr(out["reservoir_out"]),
+                                _ptr(table), _ptr(saved), _ptr(nxt), torch.cuda.current_stream(self.device).cuda_stream)
+        return table, saved, nxt
+
+    def encode_chained(self, left, right, shapes, use_huffman=True):
+        """Stream mode for MANY stereo streams at once: left/right [nStreams][samples] on the device (each row
+        starts with its zero prior hop), shapes[s] = the (offset, a, b) sequence of stream s.  Step t encodes the
+        t-th block of every stream that still has one, grouped by block shape; the bit reservoir of each stream
+        is chained from block to block ON THE DEVICE (reservoir_out + Huffman bits_saved, codecThem.py:274,503),
+        so there is no host round trip inside the loop.  Returns (steps, reservoir): steps = list of
+        (stream ids (list), a, b, outputs dict of device tensors) in encode order; reservoir [nStreams] int32."""
+        nS, stride = left.shape[0], left.shape[1]
+        if right.shape != left.shape or len(shapes) != nS:
+            raise ValueError("left/right [nStreams][samples] and one shape list per stream expected")
+        flatL, flatR = left.reshape(-1), right.reshape(-1)
+        reservoir = torch.zeros((nS,), dtype=torch.int32, device=self.device)
+        steps = []
+        for t in range(max((len(s) for s in shapes), default=0)):
+            groups = {}
+            for s in range(nS):
+                if t < len(shapes[s]):
+                    off, a, b = shapes[s][t]
+                    if off + a + b > stride:
+                        raise ValueError("stream %d is too short for its block %d" % (s, t))
+                    groups.setdefault((a, b), []).append((s, off))
+            for (a, b), members in sorted(groups.items()):
+                ids = [s for s, _ in members]
+                idx = torch.tensor(ids, dtype=torch.int64, device=self.device)
+                offs = torch.tensor([s * stride + off for s, off in members], dtype=torch.int64, device=self.device)
+                out = self.encode(a, b, flatL, flatR, len(ids), 0, offs, reservoir[idx].contiguous(), fresh=True)
+                _, _, nxt = self.huffman_gain(a, b, out, use_huffman)
+                reservoir[idx] = nxt
+                steps.append((ids, a, b, out))
+        return steps, reservoir

@@ -246,6 +246,20 @@ int mrc_dev_alloc_quant(mrc_handle* h, int a, int b, int64_t n_frames, int joint
     return MRC_OK;
 }
 
+int mrc_dev_huffman_gain(mrc_handle* h, int a, int b, int64_t n_frames, int n_streams, const int32_t* bit_alloc,
+                         const int32_t* mantissa, const int32_t* reservoir_out, int32_t* huff_table,
+                         int32_t* bits_saved, int32_t* reservoir_next, void* stream) {
+    if (!h || !bit_alloc || !mantissa || !huff_table || !bits_saved || n_frames < 0 || n_streams < 1 || n_streams > 4 ||
+        (reservoir_next && !reservoir_out))
+        return fail(h, MRC_ERR_INVALID, "mrc_dev_huffman_gain: bad argument (1 <= n_streams <= 4)");
+    const HostShape* hs;
+    int rc = get_shape(h, a, b, &hs);
+    if (rc) return rc;
+    MRC_HIP(h, launch_huffman_gain(hs->dev, n_frames, n_streams, bit_alloc, mantissa, reservoir_out, huff_table,
+                                   bits_saved, reservoir_next, pick_stream(h, stream)));
+    return MRC_OK;
+}
+
 int mrc_dev_encode(mrc_handle* h, int a, int b, int64_t n_frames, const double* ch_left, const double* ch_right,
                    int64_t frame_stride, const int64_t* offsets, const int32_t* reservoir_in,
                    int32_t* overall_scale, int32_t* ms_switch, int32_t* bit_alloc, int32_t* scale_factor,
@@ -485,6 +499,29 @@ int mrc_mantissa(mrc_handle* h, int64_t n, int n_scale_bits, const double* x, co
     MRC_HIP(h, launch_mantissa(n, n_scale_bits, h->inL.as<double>(), h->inAux.as<int>(), h->inAux2.as<int>(),
                                h->outC.as<int>(), h->stream));
     MRC_TRY(s.down(mant, h->outC, (size_t)n * sizeof(int32_t)));
+    MRC_HIP(h, hipStreamSynchronize(h->stream));
+    return MRC_OK;
+}
+
+int mrc_huffman_gain(mrc_handle* h, int64_t n, int a, int b, int n_streams, const int32_t* bit_alloc,
+                     const int32_t* mantissa, int32_t* huff_table, int32_t* bits_saved) {
+    if (!h || !bit_alloc || !mantissa || !huff_table || !bits_saved || n < 0 || n_streams < 1 || n_streams > 4)
+        return fail(h, MRC_ERR_INVALID, "mrc_huffman_gain: bad argument");
+    if (n == 0) return MRC_OK;
+    const HostShape* hs;
+    MRC_TRY(get_shape(h, a, b, &hs));
+    const DevShape& S = hs->dev;
+    MRC_HIP(h, hipSetDevice(h->device));
+    Staged s{h, h->stream};
+    const size_t szBa = (size_t)n * n_streams * S.nBands * sizeof(int32_t);
+    const size_t szM = (size_t)n * n_streams * S.halfN * sizeof(int32_t), szOut = (size_t)n * n_streams * sizeof(int32_t);
+    MRC_TRY(s.up(h->inAux, bit_alloc, szBa));
+    MRC_TRY(s.up(h->inL, mantissa, szM));
+    MRC_HIP(h, h->outC.reserve(szOut)); MRC_HIP(h, h->outD.reserve(szOut));
+    MRC_HIP(h, launch_huffman_gain(S, n, n_streams, h->inAux.as<int>(), h->inL.as<int>(), nullptr, h->outC.as<int>(),
+                                   h->outD.as<int>(), nullptr, h->stream));
+    MRC_TRY(s.down(huff_table, h->outC, szOut));
+    MRC_TRY(s.down(bits_saved, h->outD, szOut));
     MRC_HIP(h, hipStreamSynchronize(h->stream));
     return MRC_OK;
 }

@@ -75,6 +75,10 @@ hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, con
                               int* bitAlloc, int* scaleFactor, int* mantissa, int* resOut, double* bandPeakWs,
                               hipStream_t st);
 size_t alloc_workspace_bytes(const DevShape& S, int64_t nFrames, int joint);   // bandPeakWs size
+// mrc_kernels_huff.hip
+hipError_t launch_huffman_gain(const DevShape& S, int64_t nFrames, int nStreams, const int* bitAlloc,
+                               const int* mantissa, const int* reservoirOut, int* huffTable, int* bitsSaved,
+                               int* reservoirNext, hipStream_t st);
 hipError_t launch_bitalloc_cases(int64_t nCases, int nBands, int maxMantBits, const int* nLines,
                                  const double* budget, const double* smr, int* bits, int* left, hipStream_t st);
 hipError_t launch_scale_factor(int64_t n, int nScaleBits, const double* v, const int* nMantBits, int* out,

@@ -129,3 +129,59 @@ def encode_stereo_stream(handle, stream, shapes, use_huffman=True, num_samples=N
         reservoir = int(r["reservoir_out"][0]) + int(saved.sum())
         out.append(data.tobytes())
     return b"".join(out)
+
+
+def encode_stereo_streams(handle, streams, shapes, use_huffman=True, num_samples=None):
+    """encode_stereo_stream for MANY stereo streams at once (stream mode): streams [nStreams][2][samples],
+    shapes[s] = block-shape sequence of stream s, num_samples[s] (optional) = the header's sample count.
+    All streams advance one block per step on the GPU with their bit reservoirs chained on the device
+    (batch.StreamEncoder.encode_chained: kernels + Huffman pricing, no host round trip per block); the
+    bytes are packed afterwards by the threaded C++ packer, one call per (step, block shape).  Returns a list
+    of .pac byte strings, each identical to what encode_stereo_stream gives for that stream alone."""
+    import torch
+    from .batch import StreamEncoder
+    c = handle.cfg
+    cfg = make_config(c.sample_rate, c.n_mdct_lines, c.n_short, c.n_scale_bits, c.n_mant_size_bits,
+                      c.target_bits_per_sample, c.blksw_bits_a, c.blksw_bits_b)
+    L = c.n_mdct_lines
+    streams = np.asarray(streams, dtype=np.float64)
+    nS = streams.shape[0]
+    if streams.ndim != 3 or streams.shape[1] != 2 or len(shapes) != nS:
+        raise ValueError("streams [nStreams][2][samples] and one shape list per stream expected")
+    for sh in shapes:
+        if not sh or sh[-1][2] != L:
+            raise ValueError("every stream must end with a long block (the reference's Close() assumes it)")
+    enc = StreamEncoder(handle)
+    dev = enc.device
+    left = torch.from_numpy(np.ascontiguousarray(streams[:, 0])).to(dev)
+    right = torch.from_numpy(np.ascontiguousarray(streams[:, 1])).to(dev)
+    steps, reservoir = enc.encode_chained(left, right, shapes, use_huffman)
+
+    # Close(): one more (L, L) block per channel, the last hop followed by zeros, through the non-joint writer
+    flush = torch.zeros((2, nS, 2 * L), dtype=torch.float64, device=dev)
+    tail = torch.tensor([sh[-1][0] + sh[-1][1] for sh in shapes], dtype=torch.int64, device=dev)
+    cols = tail[:, None] + torch.arange(L, device=dev)[None, :]
+    flush[0, :, :L] = torch.gather(left, 1, cols)
+    flush[1, :, :L] = torch.gather(right, 1, cols)
+    closing = []
+    for ch in range(2):
+        out = enc.encode(L, L, flush[ch].reshape(-1), None, nS, 2 * L, None, reservoir.contiguous(), fresh=True)
+        _, _, reservoir = enc.huffman_gain(L, L, out, use_huffman)
+        closing.append(out)
+    torch.cuda.synchronize(dev)
+
+    parts = [[header(cfg, 2, sum(b for (_, _, b) in sh) if num_samples is None else num_samples[s])]
+             for s, sh in enumerate(shapes)]
+    host = lambda o, k: o[k].cpu().numpy()
+    for ids, a, b, out in steps:
+        data, offs, _, _ = pack_joint_blocks(cfg, a, b, host(out, "overall_scale"), host(out, "ms_switch"),
+                                             host(out, "scale_factor"), host(out, "bit_alloc"), host(out, "mantissa"),
+                                             use_huffman)
+        for i, s in enumerate(ids):
+            parts[s].append(data[offs[i]:offs[i + 1]].tobytes())
+    for out in closing:
+        data, offs, _, _ = pack_blocks(cfg, L, L, host(out, "overall_scale"), host(out, "scale_factor"),
+                                       host(out, "bit_alloc"), host(out, "mantissa"), use_huffman)
+        for s in range(nS):
+            parts[s].append(data[offs[s]:offs[s + 1]].tobytes())
+    return [b"".join(p) for p in parts]

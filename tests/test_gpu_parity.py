@@ -356,3 +356,61 @@ def test_training_script_parameters_44k():
         _assert_int_parity(hd.encode_joint(bl, br, 1024, 1024), fast.encode_joint_batch(bl, br, 1024, 1024, params=P), joint=True)
     finally:
         hd.close()
+
+
+# ------------------------------------------------------------------ stream mode: many streams, reservoirs chained on the device
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1024, 1024), (128, 128), (1024, 128)])
+def test_huffman_pricing_kernel_vs_packer(h, shape):
+    # the device-side table PRICING (table id, bits_saved) against the C++ packer's choice, which test_pack.py
+    # pins to the oracle's calculateHuffmanGain; values cover every table entry, the escape values and beyond
+    from mrcaudiocodec_amd import pacfile as ppac
+    a, b = shape
+    cfg = ppac.make_config()
+    bands = ppac.band_table(cfg, a, b)
+    nb, M, n = len(bands), (a + b) // 2, 40
+    rng = np.random.default_rng(5)
+    ba = rng.integers(0, 9, size=(n, 2, nb)).astype(np.int32)
+    ba[ba == 1] = 0
+    ba[:4] = 0                                                  # empty chunks: raw wins with 0 bits
+    line_band = np.repeat(np.arange(nb), bands)
+    scale = np.array([1, 2, 3, 5, 9, 17, 33, 65, 70, 200])[rng.integers(0, 10, size=(n, 2, 1))]
+    mant = (rng.integers(0, 1 << 16, size=(n, 2, M)) % scale).astype(np.int32)
+    mant = np.minimum(mant, (1 << np.maximum(ba[:, :, line_band], 1)) - 1).astype(np.int32)
+    mant[ba[:, :, line_band] == 0] = 0
+    osc = np.zeros((n, 2), np.int32)
+    sf = np.zeros((n, 2, nb), np.int32)
+    _, _, table, saved = ppac.pack_blocks(cfg, a, b, osc, sf, ba, mant, True)
+    gt, gs = h.huffman_gain(ba, mant, a, b)
+    assert np.array_equal(gt, table)
+    assert np.array_equal(gs, saved)
+    assert len(set(table.ravel().tolist())) >= 3                # several tables and raw are exercised
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("huff", [True, False])
+def test_pac_bytes_many_streams_chained_on_device(h, huff):
+    # stream mode: streams with DIFFERENT block-shape sequences advance together, reservoirs chained on the
+    # device through the Huffman pricing kernel; every .pac must equal the oracle's single-stream result
+    pytest.importorskip("torch")
+    from mrcaudiocodec_amd import pacfile as ppac, synth
+    from oracle import pacfile as opac
+    hops = 11
+    x, sh_sw = synth.c4_transients(hops)
+    tone = synth.c1_sine(hops)
+    g = synth.c2_noise(hops, seed=3, sigma=0.05)
+    sh_long = [(i * 1024, 1024, 1024) for i in range(hops - 1)]
+    n = len(tone)
+    streams = np.stack([
+        np.stack([x + 0.3 * tone, 0.7 * x + 0.3 * tone + 0.05 * g])[:, :n],
+        np.stack([tone, 0.9 * tone]),
+        np.stack([0.5 * tone + g, 0.5 * tone - g]),
+        np.stack([g, 0.2 * tone]),
+    ])
+    shapes = [sh_sw, sh_long, sh_long[:6], sh_sw]
+    got = ppac.encode_stereo_streams(h, streams, shapes, use_huffman=huff)
+    for s in range(len(shapes)):
+        want = opac.encode_stereo_stream(streams[s], shapes[s], huffman=huff)
+        assert got[s] == want, s
+    # and the single-stream driver gives the same bytes
+    assert got[1] == ppac.encode_stereo_stream(h, streams[1], shapes[1], use_huffman=huff)
