@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmrc_hip.so")
+LIB_PATH = os.environ.get("MRC_HIP_LIBRARY") or os.path.join(_HERE, "libmrc_hip.so")   # override: profiling builds
 
 MRC_MAX_BANDS = 32
 _i32p = C.POINTER(C.c_int32)

@@ -94,22 +94,44 @@ template <> __device__ __forceinline__ void butterfly<4>(double2* u) {
     u[3] = make_double2(b.x - d.y, b.y + d.x);
 }
 
+// Twiddle source of the block FFT.  TwGlobal: the full table exp(-2 pi i t/n) in global memory (any n).
+// TwQuarter: its first quadrant staged in LDS, n a power of two: w(s + q n/4) = w(s) (-i)^q -- same values, but no
+// global-load latency inside the passes (the FFT of a block is a chain of dependent, barrier-separated passes).
+struct TwGlobal {
+    const double2* __restrict__ w;
+    __device__ __forceinline__ double2 operator()(int t) const { return w[t]; }
+};
+struct TwQuarter {
+    const double2* w;                                   // LDS, [n/4]
+    int mask, shift;                                    // n/4 - 1, log2(n/4)
+    __device__ __forceinline__ double2 operator()(int t) const {
+        const double2 v = w[t & mask];
+        const int q = t >> shift;                       // 0..2 (t < 3n/4)
+        double2 r = (q & 1) ? make_double2(v.y, -v.x) : v;
+        if (q & 2) r = make_double2(-r.x, -r.y);
+        return r;
+    }
+};
+
 // POW2: p (the product of the radices already done) is a power of two -- true until the first radix-3
 // pass, factor() puts the 3s last -- so the index split is a mask and a shift instead of div/mod.
-template <int R, bool POW2>
+// The first pass (p == 1) has unit twiddles and skips them.
+template <int R, bool POW2, class TW>
 __device__ __forceinline__ void fft_pass(const double2* __restrict__ in, double2* __restrict__ out, int n, int p,
-                                         const double2* __restrict__ W, int tid) {
+                                         const TW& W, int tid) {
     const int T = n / R;
     const int tws = n / (p * R);
     const int lp = 31 - __clz(p);
+    const bool first = p == 1;
     for (int i = tid; i < T; i += kThreads) {
         const int k = POW2 ? (i & (p - 1)) : (i % p);
         const int j = (POW2 ? (i >> lp) : (i / p)) * (p * R) + k;
         double2 u[R];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            u[r] = in[i + r * T];
-            if (r > 0) u[r] = cmul(u[r], W[k * r * tws]);
+        for (int r = 0; r < R; ++r) u[r] = in[i + r * T];
+        if (!first) {
+#pragma unroll
+            for (int r = 1; r < R; ++r) u[r] = cmul(u[r], W(k * r * tws));
         }
         butterfly<R>(u);
 #pragma unroll
@@ -118,8 +140,9 @@ __device__ __forceinline__ void fft_pass(const double2* __restrict__ in, double2
 }
 
 // Runs all passes; returns the buffer (A or B) that holds the natural-order result.
-__device__ double2* fft_lds(double2* A, double2* B, int n, const int* rad, int nrad, const double2* __restrict__ W,
-                            int tid) {
+template <class TW>
+__device__ __forceinline__ double2* fft_lds(double2* A, double2* B, int n, const int* rad, int nrad, const TW& W,
+                                            int tid) {
     int p = 1;
     for (int s = 0; s < nrad; ++s) {
         const int R = rad[s];
@@ -135,6 +158,24 @@ __device__ double2* fft_lds(double2* A, double2* B, int n, const int* rad, int n
         p *= R;
     }
     return A;
+}
+// n a power of two (radix 4 / 2 passes only), twiddles from the LDS quadrant
+__device__ __forceinline__ double2* fft_lds_pow2(double2* A, double2* B, int n, const int* rad, int nrad,
+                                                 const TwQuarter& W, int tid) {
+    int p = 1;
+    for (int s = 0; s < nrad; ++s) {
+        const int R = rad[s];
+        if (R == 4) fft_pass<4, true>(A, B, n, p, W, tid);
+        else fft_pass<2, true>(A, B, n, p, W, tid);
+        __syncthreads();
+        double2* t = A; A = B; B = t;
+        p *= R;
+    }
+    return A;
+}
+__device__ __forceinline__ double2* fft_lds(double2* A, double2* B, int n, const int* rad, int nrad,
+                                            const double2* __restrict__ W, int tid) {
+    return fft_lds(A, B, n, rad, nrad, TwGlobal{W}, tid);
 }
 
 // NumPy's pairwise summation of a contiguous run (np.sum over a 1-D slice), restated so that the

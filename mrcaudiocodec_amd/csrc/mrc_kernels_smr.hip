@@ -20,6 +20,7 @@
 //                 Same integers as EXACT on every parity corpus, thresholds within 1e-10 dB
 //                 (tests/test_gpu_parity.py::test_spread_modes_agree).
 #include "mrc_device.hpp"
+#include "mrc_log10.hpp"
 
 namespace mrc {
 using namespace dev;
@@ -151,6 +152,26 @@ __device__ __forceinline__ void wave_sum_16(double* v, int lane) {
     for (int j = 0; j < 16; ++j) v[j] = __shfl(s, j << 2);
 }
 
+// kLog10Tab as [j][4] for the LDS copy
+struct LogTabDev { double v[kLogTabEntries * 4]; };
+constexpr LogTabDev make_log_tab() {
+    LogTabDev t{};
+    for (int j = 0; j < kLogTabEntries; ++j)
+        for (int c = 0; c < 3; ++c) t.v[4 * j + c] = kLog10Tab[j][c];
+    return t;
+}
+__constant__ LogTabDev kLogTabDev = make_log_tab();
+
+// psychoac.py:8-12 with the table-driven log10 (mrc_log10.hpp); zero, denormal, inf and nan take the library path
+__device__ __forceinline__ double spl_db_tab(double intensity, const double* __restrict__ tab) {
+    if (!(intensity >= 0x1p-1022 && intensity <= 0x1.fffffffffffffp+1023)) return spl_db(intensity);
+    return fmax(96 + 10 * log10_tab32(intensity, tab), -30.0);
+}
+
+// Where the staged tables sit in the dynamic LDS (offsets in doubles, chosen by launch_smr): the Bark grid of the
+// lines for the masker-side searches, the log10 table, the first quadrant of the FFT twiddles (-1: use global).
+struct SmrLds { int zbOff, logOff, twOff; };
+
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
 #pragma unroll
     for (int off = 1; off < kWave; off <<= 1) {
@@ -160,13 +181,35 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
     return v;
 }
 
+#ifdef MRC_PROFILE_PHASES
+// profiling build only (make EXTRA=-DMRC_PROFILE_PHASES): shader-clock cycles per kernel phase, summed over waves
+__device__ unsigned long long gPhaseCycles[16];
+#define MRC_PHASE(i)                                                                  \
+    do {                                                                              \
+        const long long now_ = clock64();                                             \
+        if (lane == 0) atomicAdd(&gPhaseCycles[i], (unsigned long long)(now_ - tPhase_)); \
+        tPhase_ = clock64();                                                          \
+    } while (0)
+#else
+#define MRC_PHASE(i) do { } while (0)
+#endif
+
+#ifndef MRC_SMR_WAVES_PER_EU                     // 4 workgroups of 4 waves per CU (what the LDS footprint allows): <= 128 VGPRs
+#define MRC_SMR_WAVES_PER_EU 4
+#endif
+#if MRC_SMR_WAVES_PER_EU > 0
+#define MRC_SMR_OCC __attribute__((amdgpu_waves_per_eu(MRC_SMR_WAVES_PER_EU, MRC_SMR_WAVES_PER_EU)))
+#else
+#define MRC_SMR_OCC
+#endif
+
 template <bool EXACT>
-__global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, const double* __restrict__ chL,
+__global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, int nsig, const double* __restrict__ chL,
                                                        const double* __restrict__ chR, int64_t stride,
                                                        const int64_t* __restrict__ offsets,
                                                        const double* __restrict__ lines,
                                                        const int* __restrict__ oscale, double* __restrict__ smr,
-                                                       double* __restrict__ thresh) {
+                                                       double* __restrict__ thresh, SmrLds lay) {
     extern __shared__ double smem[];
     __shared__ int waveCnt[kThreads / kWave];
     __shared__ double e2tab[16];                        // 2^(j/16)
@@ -187,29 +230,73 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
     double* piHi = reinterpret_cast<double*>(nUpArr + (M + 2));          // [<= peakLast/2 + 2] prefix sums of the masker
     double* piLo = piHi + (S.peakLast / 2 + 2);                          //   intensities, double-double (hi, lo)
 
+#ifdef MRC_PROFILE_PHASES
+    long long tPhase_ = clock64();
+#endif
     if (tid < kMaxBands) bandKey[tid] = 0ull;           // below every key; visible after the first barrier
     if (tid < 16) e2tab[tid] = kExp2Sixteenths[tid];
-    // Hann window (window.py:28-45) and real FFT through an H = N/2 point complex FFT
-    for (int n = tid; n < H; n += kThreads) {
-        double e = load_signal(chL, chR, off + 2 * n, sig) * S.hann[2 * n];
-        double o = load_signal(chL, chR, off + 2 * n + 1, sig) * S.hann[2 * n + 1];
-        A[n] = make_double2(e, o);
+    const double* zbS = smem + lay.zbOff;               // staged after the FFT (the area is FFT scratch / dead)
+    const double* logTab = smem + lay.logOff;
+    // Hann window (window.py:28-45) and real FFT through an H = N/2 point complex FFT.  All global loads of a
+    // thread are issued before the first use: one memory round trip per phase instead of one per iteration.
+    constexpr int kPre = 4;
+    for (int n0 = tid; n0 < H; n0 += kThreads * kPre) {
+        double e[kPre], o[kPre], he[kPre], ho[kPre];
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const int n = min(n0 + u * kThreads, H - 1);
+            e[u] = load_signal(chL, chR, off + 2 * n, sig);
+            o[u] = load_signal(chL, chR, off + 2 * n + 1, sig);
+            he[u] = S.hann[2 * n];
+            ho[u] = S.hann[2 * n + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const int n = n0 + u * kThreads;
+            if (n < H) A[n] = make_double2(e[u] * he[u], o[u] * ho[u]);
+        }
     }
-    __syncthreads();
-    double2* T = fft_lds(A, B, H, S.radH, S.nRadH, S.wH, tid);
     const int last = S.peakLast;                        // bins 0 .. last-1 are inspected (psychoac.py:160)
-    for (int k = tid; k < last; k += kThreads) {
-        double2 zk = T[k];
-        double2 zc = T[(H - k) % H];
-        zc.y = -zc.y;
-        double2 ev = make_double2(0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y));
-        double2 d = make_double2(zk.x - zc.x, zk.y - zc.y);
-        double2 od = make_double2(0.5 * d.y, -0.5 * d.x);
-        double2 X = cmul(S.wN[k], od);
-        X.x += ev.x; X.y += ev.y;
-        xi[k] = 4. * (X.x * X.x + X.y * X.y) / S.xiDen;  // psychoac.py:151
+    double2* T;
+    if (lay.twOff >= 0) {
+        double2* Wq = reinterpret_cast<double2*>(smem + lay.twOff);
+        for (int t = tid; t < H / 4; t += kThreads) Wq[t] = S.wH[t];
+        __syncthreads();
+        MRC_PHASE(0);
+        T = fft_lds_pow2(A, B, H, S.radH, S.nRadH, TwQuarter{Wq, H / 4 - 1, 31 - __clz(H / 4)}, tid);
+    } else {
+        __syncthreads();
+        MRC_PHASE(0);
+        T = fft_lds(A, B, H, S.radH, S.nRadH, S.wH, tid);
+    }
+    MRC_PHASE(1);
+    for (int k0 = tid; k0 < last; k0 += kThreads * kPre) {
+        double2 wn[kPre];
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) wn[u] = S.wN[min(k0 + u * kThreads, last - 1)];
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const int k = k0 + u * kThreads;
+            if (k < last) {
+                double2 zk = T[k];
+                double2 zc = T[(H - k) % H];
+                zc.y = -zc.y;
+                double2 ev = make_double2(0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y));
+                double2 d = make_double2(zk.x - zc.x, zk.y - zc.y);
+                double2 od = make_double2(0.5 * d.y, -0.5 * d.x);
+                double2 X = cmul(wn[u], od);
+                X.x += ev.x; X.y += ev.y;
+                xi[k] = 4. * (X.x * X.x + X.y * X.y) / S.xiDen;  // psychoac.py:151
+            }
+        }
     }
     __syncthreads();                                    // T (in A or B) is dead from here on
+    MRC_PHASE(2);
+    if (!EXACT) {                                       // stage the Bark grid and the log10 table (used after 2 barriers)
+        double* zw = smem + lay.zbOff;
+        for (int k = tid; k < M; k += kThreads) zw[k] = S.zb[k];
+        if (tid < kLogTabEntries * 4) smem[lay.logOff + tid] = kLogTabDev.v[tid];
+    }
 
     // tonal maskers: strict 3-point peaks at bins p = 1 .. last-2, kept in increasing bin order.
     // Table (aliases A), 4 doubles per masker:
@@ -238,13 +325,14 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
     if (!EXACT)
         for (int k = tid; k <= M; k += kThreads) { cntArr[k] = 0; nUpArr[k] = 0; }
     __syncthreads();
+    MRC_PHASE(3);
     for (int mi = tid; mi < nPeaks; mi += kThreads) {
         const int p = pkBin[mi];
         const int before = mi;
         double x0 = xi[p - 1], x1 = xi[p], x2 = xi[p + 1];
         {
             double s3 = (x0 + x1) + x2;
-            double level = spl_db(s3);                                       // psychoac.py:164
+            double level = EXACT ? spl_db(s3) : spl_db_tab(s3, logTab);      // psychoac.py:164
             double fm = S.binHz * (((p - 1) * x0 + p * x1) + (p + 1) * x2) / s3;   // psychoac.py:165
             double q = fm / 7500.;
             const double zm = 13 * atan(0.76 * fm / 1000.) + 3.5 * atan(q * q);     // psychoac.py:27-29
@@ -270,19 +358,20 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
                 int lo = 0, hi = M;
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
-                    if (S.zb[mid] - zm >= -0.5) hi = mid; else lo = mid + 1;
+                    if (zbS[mid] - zm >= -0.5) hi = mid; else lo = mid + 1;
                 }
                 atomicAdd(reinterpret_cast<unsigned int*>(cntArr) + (lo >> 1), 1u << (16 * (lo & 1)));
                 hi = M;
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
-                    if (S.zb[mid] - zm > 0.5) hi = mid; else lo = mid + 1;
+                    if (zbS[mid] - zm > 0.5) hi = mid; else lo = mid + 1;
                 }
                 atomicAdd(reinterpret_cast<unsigned int*>(nUpArr) + (lo >> 1), 1u << (16 * (lo & 1)));
             }
         }
     }
     __syncthreads();
+    MRC_PHASE(4);
 
     // psychoac.py:214-217: SMR of a band = max over its lines of (SPL of the line - masked threshold),
     // accumulated with LDS integer max-atomics on an order-preserving key (initialised by the table
@@ -399,6 +488,7 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
             }
         }
         __syncthreads();
+        MRC_PHASE(5);
 
         // Each wave sweeps 64-line chunks (one line per lane); the chunk order pairs cheap (low) with
         // expensive (high) chunks so the four waves finish together.  Per line, the Bark-sorted maskers
@@ -431,6 +521,7 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
 #endif
             const int mPlain = min(mExp, mLow);
             const double zq = z - 0.5;                 // u = max(z - z_m - 1/2, 0), one subtraction per pair
+            MRC_PHASE(6);
 
             // ---- far field by local expansion.  Maskers [0, nFar) lie more than 1/2 Bark below EVERY line
             // of the chunk, so their sum  sum_m I_m 2^(s_m (z - z_m - 1/2))  is smooth in z over the chunk:
@@ -481,6 +572,7 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
                 }
             }
 #endif
+            MRC_PHASE(7);
             // some line of the chunk is above the masker's band, every line sees the masker
 #pragma unroll 4
             for (int m = mFirst; m < mPlain; ++m) {
@@ -488,12 +580,14 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
                 const double u = fmax(zq - zm, 0.0);
                 tot = fma(I, exp2_tab16(sl, u, e2tab), tot);
             }
+            MRC_PHASE(8);
             // same, but part of the chunk lies below the masker's band (only when the chunk spans > 1 Bark)
             for (int m = mPlain; m < mExp; ++m) {
                 const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
                 const double u = fmax(zq - zm, 0.0);
                 tot = fma(m < cnt ? I : 0.0, exp2_tab16(sl, u, e2tab), tot);
             }
+            MRC_PHASE(9);
             // no line of the chunk is above the band: every line that sees the masker is inside +-1/2 Bark
             if (cnt > mExp) {
                 // sum of I_m over [mExp, cnt) = pi[cnt] - pi[mExp], in double-double
@@ -505,10 +599,10 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
             }
             // maskers more than 1/2 Bark above the line: -27 dB/Bark for all of them
             const double t = fma(S.lowE[kc], sc[cnt], tot);
-            const double thr = spl_db(t);                                    // psychoac.py:173
+            const double thr = spl_db_tab(t, logTab);                        // psychoac.py:173
             if (thresh && k < M) thresh[(int64_t)blockIdx.x * M + k] = thr;
             const double xs = ldexp(X[kc], scale);                           // codecThem.py:323 (exact)
-            const double spl = spl_db(2. * (xs * xs) / (1. / 2.)) - 6. * scale;      // psychoac.py:212
+            const double spl = spl_db_tab(2. * (xs * xs) / (1. / 2.), logTab) - 6. * scale;      // psychoac.py:212
             const double ex = spl - thr;                 // lanes past the end repeat the last line: max unchanged
             const int bnd = S.bandOfLine[kc];
             if (__all(bnd == __builtin_amdgcn_readfirstlane(bnd))) {
@@ -517,27 +611,65 @@ __global__ __launch_bounds__(kThreads) void smr_kernel(DevShape S, int nsig, con
             } else {
                 atomicMax(&bandKey[bnd], order_key(ex));
             }
+            MRC_PHASE(10);
         }
     }
     __syncthreads();
+    MRC_PHASE(11);
     for (int bnd = tid; bnd < S.nBands; bnd += kThreads)
         smr[(int64_t)blockIdx.x * S.nBands + bnd] = order_value(bandKey[bnd]);
 }
 
 }  // namespace
 
+#ifdef MRC_PROFILE_PHASES
+extern "C" int mrc_debug_phase_cycles(unsigned long long* out16, int reset) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(gPhaseCycles), sizeof(unsigned long long) * 16);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[16] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(gPhaseCycles), z, sizeof z);
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif
+
 hipError_t launch_smr(const DevShape& S, int64_t nFrames, const double* chL, const double* chR, int64_t stride,
                       const int64_t* offsets, const double* lines, const int* oscale, double* smr, double* thresh,
                       bool exactSpread, hipStream_t st) {
     if (nFrames <= 0) return hipSuccess;
     const int nsig = chR ? 4 : 1;
-    size_t lds = (size_t)(4 * S.H + S.peakLast + 1) * sizeof(double);
+    // dynamic LDS (doubles): FFT ping-pong [4H] + intensity spectrum [peakLast + 1].  The staged tables go into
+    // areas that are dead when they are needed if there is room (the long block is sized for 4 workgroups per CU
+    // and must not grow), else behind the spectrum.
+    const int H = S.H, M = S.halfN;
+    int total = 4 * H + S.peakLast + 1;
+    const int pkShorts = (S.peakLast / 2 + 5) & ~3;
+    const int piOff = 2 * H + (pkShorts * 2 + 2 * (M + 2) * 2) / 8;          // where piHi starts (kernel layout)
+    const int piLen = 2 * (S.peakLast / 2 + 2);
+    const int logLen = kLogTabEntries * 4;
+    SmrLds lay;
+    if (piOff + std::max(piLen, M) + logLen <= 4 * H) {
+        lay.zbOff = piOff;                               // overwritten by the prefix sums after the searches
+        lay.logOff = 4 * H - logLen;
+    } else {
+        total += total & 1;
+        lay.zbOff = total;
+        lay.logOff = total + M;
+        total += M + logLen;
+    }
+    lay.twOff = -1;
+    if ((H & (H - 1)) == 0 && H >= 16) {                 // first quadrant of the FFT twiddles: in the spectrum area
+        if (H / 2 <= S.peakLast + 1) lay.twOff = 4 * H;
+        else { total += total & 1; lay.twOff = total; total += H / 2; }
+    }
+    const size_t lds = (size_t)total * sizeof(double);
     if (exactSpread)
         hipLaunchKernelGGL(smr_kernel<true>, dim3((unsigned)(nFrames * nsig)), dim3(kThreads), lds, st, S, nsig, chL,
-                           chR, stride, offsets, lines, oscale, smr, thresh);
+                           chR, stride, offsets, lines, oscale, smr, thresh, lay);
     else
         hipLaunchKernelGGL(smr_kernel<false>, dim3((unsigned)(nFrames * nsig)), dim3(kThreads), lds, st, S, nsig, chL,
-                           chR, stride, offsets, lines, oscale, smr, thresh);
+                           chR, stride, offsets, lines, oscale, smr, thresh, lay);
     return hipGetLastError();
 }
 

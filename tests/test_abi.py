@@ -89,3 +89,16 @@ def test_synth_shapes():
     assert shapes[-1][0] + shapes[-1][1] + shapes[-1][2] == len(x)
     assert np.abs(x).max() <= 1.0
     assert synth.pcm_to_float([1])[0] == 3.0518043793392844e-05
+
+
+def test_table_log10_accuracy(tmp_path):
+    # mrc_log10.hpp (the SPL conversions of smr_kernel) compiled for the HOST: <= 0.6 ulp against long double
+    # wherever |log10 x| >= 1/4 and <= 4e-17 absolute near x = 1 (the value is added to 96 afterwards)
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "log10_check")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-I", os.path.join(root, "mrcaudiocodec_amd", "csrc"),
+                           os.path.join(root, "tests", "log10_check.cpp"), "-o", exe])
+    max_ulp, max_abs = map(float, subprocess.check_output([exe]).split())
+    assert max_ulp <= 0.6, max_ulp
+    assert max_abs <= 4e-17, max_abs
