@@ -498,13 +498,24 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
         // three scalar loops.
         const int nChunks = (M + kWave - 1) / kWave;
         const int nWaves = kThreads / kWave;
+        // the per-line constants of the NEXT chunk are loaded while this one is computed (loop-carried, so the
+        // global-load latency is never exposed between the loops of a chunk)
+        struct LineConst { double z, quiet, lowE, x; int bnd; };
+        auto chunk_of = [&](int i) { return i * nWaves + ((i & 1) ? (nWaves - 1 - wave) : wave); };
+        auto load_consts = [&](int i) {
+            const int kc = min(chunk_of(i) * kWave + lane, M - 1);
+            return LineConst{S.zb[kc], S.quiet[kc], S.lowE[kc], X[kc], S.bandOfLine[kc]};
+        };
+        LineConst nxt = load_consts(0);
         for (int i = 0;; ++i) {
-            const int c = i * nWaves + ((i & 1) ? (nWaves - 1 - wave) : wave);
+            const int c = chunk_of(i);
             if (c >= nChunks) break;
             const int k = c * kWave + lane;
             const int kc = min(k, M - 1);
-            const double z = S.zb[kc];
-            double tot = S.quiet[kc];
+            const LineConst cur = nxt;
+            nxt = load_consts(i + 1);
+            const double z = cur.z;
+            double tot = cur.quiet;
             const int cnt = cntArr[kc], nUp = nUpArr[kc];      // maskers that reach the line / lie > 1/2 Bark below it
             int mLow = cnt, mEnd = cnt, mExp = nUp;
 #pragma unroll
@@ -516,8 +527,8 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
             mLow = __builtin_amdgcn_readfirstlane(mLow);
             mEnd = __builtin_amdgcn_readfirstlane(mEnd);
             mExp = __builtin_amdgcn_readfirstlane(mExp);
-#ifdef MRC_PROFILE_SKIP_SPREAD                  // profiling aid: everything but the spreading loops (wrong results)
-            mLow = mEnd = mExp = 0;
+#ifndef MRC_PROFILE_SKIP                         // profiling aid (wrong results): bit mask of sweep parts to leave out,
+#define MRC_PROFILE_SKIP 0                       // 1 far field, 2 direct pairs, 4 partial pairs, 8 chunk tail
 #endif
             const int mPlain = min(mExp, mLow);
             const double zq = z - 0.5;                 // u = max(z - z_m - 1/2, 0), one subtraction per pair
@@ -531,7 +542,6 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
             // wave-reduced, every line evaluates the degree-J polynomial.  |a| <= 8.97 ln2 and |d| <= kFarSpan/2
             // give |a d| <= 0.7: the truncated tail is < 1.3e-17 of each term (relative, term by term).
             int mFirst = 0;
-#ifndef MRC_PROFILE_SKIP_SPREAD
             {
                 const double zFirst = __shfl(z, 0), zLast = __shfl(z, kWave - 1);
                 const double zHalfEnd = __shfl(z, kWave / 2 - 1), zHalfBeg = __shfl(z, kWave / 2);
@@ -545,6 +555,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                         const double c = (nGroups == 1) ? 0.5 * (zFirst + zLast)
                                                         : (g == 0 ? 0.5 * (zFirst + zHalfEnd) : 0.5 * (zHalfBeg + zLast));
                         const double cq = c - 0.5;
+                        if (MRC_PROFILE_SKIP & 1) continue;
                         double B[kFarOrder + 1];
 #pragma unroll
                         for (int j = 0; j <= kFarOrder; ++j) B[j] = 0.0;
@@ -571,24 +582,27 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                     mFirst = nFar;
                 }
             }
-#endif
             MRC_PHASE(7);
             // some line of the chunk is above the masker's band, every line sees the masker
 #pragma unroll 4
-            for (int m = mFirst; m < mPlain; ++m) {
+            for (int m = mFirst; m < ((MRC_PROFILE_SKIP & 2) ? 0 : mPlain); ++m) {
                 const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
                 const double u = fmax(zq - zm, 0.0);
                 tot = fma(I, exp2_tab16(sl, u, e2tab), tot);
             }
             MRC_PHASE(8);
             // same, but part of the chunk lies below the masker's band (only when the chunk spans > 1 Bark)
-            for (int m = mPlain; m < mExp; ++m) {
+            for (int m = mPlain; m < ((MRC_PROFILE_SKIP & 4) ? 0 : mExp); ++m) {
                 const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
                 const double u = fmax(zq - zm, 0.0);
                 tot = fma(m < cnt ? I : 0.0, exp2_tab16(sl, u, e2tab), tot);
             }
             MRC_PHASE(9);
             // no line of the chunk is above the band: every line that sees the masker is inside +-1/2 Bark
+            if (MRC_PROFILE_SKIP & 8) {
+                if (tot + cur.lowE + cur.x == 12345.0 && cur.bnd == 77) bandKey[0] = 1;      // keep the loads alive
+                continue;
+            }
             if (cnt > mExp) {
                 // sum of I_m over [mExp, cnt) = pi[cnt] - pi[mExp], in double-double
                 const double ah = piHi[cnt], al = piLo[cnt], bh = piHi[mExp], bl = piLo[mExp];
@@ -598,13 +612,13 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                 tot += d1 + e;
             }
             // maskers more than 1/2 Bark above the line: -27 dB/Bark for all of them
-            const double t = fma(S.lowE[kc], sc[cnt], tot);
+            const double t = fma(cur.lowE, sc[cnt], tot);
             const double thr = spl_db_tab(t, logTab);                        // psychoac.py:173
             if (thresh && k < M) thresh[(int64_t)blockIdx.x * M + k] = thr;
-            const double xs = ldexp(X[kc], scale);                           // codecThem.py:323 (exact)
+            const double xs = ldexp(cur.x, scale);                           // codecThem.py:323 (exact)
             const double spl = spl_db_tab(2. * (xs * xs) / (1. / 2.), logTab) - 6. * scale;      // psychoac.py:212
             const double ex = spl - thr;                 // lanes past the end repeat the last line: max unchanged
-            const int bnd = S.bandOfLine[kc];
+            const int bnd = cur.bnd;
             if (__all(bnd == __builtin_amdgcn_readfirstlane(bnd))) {
                 const double best = wave_max(ex);        // whole chunk inside one band (the wide top bands)
                 if (lane == 0) atomicMax(&bandKey[bnd], order_key(best));

@@ -145,3 +145,33 @@ for N in (2048, 1152, 256, 8):
     w["sine_%d" % N] = rw.SineWindow(x)
 np.savez_compressed(os.path.join(OUT, "window.npz"), **w)
 print("golden vectors written to", OUT)
+
+# ------------------------------------------------------------------ decode side ("next" row f-4)
+# vDequantize / vDequantizeUniform (quantize.py:90-111, 325-357) and ReconstructLR (ms_stereo.py:33-49)
+d = {}
+dq_cases, dq_in, dq_out = [], [], []
+for nScaleBits in (3, 4):
+    cap = (1 << nScaleBits) - 1
+    for nMantBits in (2, 3, 4, 5, 8, 12, 16):
+        for scale in sorted({0, 1, cap // 2, cap - 1, cap}):
+            mant = np.concatenate([[0, 1, (1 << (nMantBits - 1)) - 1, 1 << (nMantBits - 1), (1 << nMantBits) - 1],
+                                   rng.integers(0, 1 << nMantBits, 27)]).astype(np.int32)
+            dq_cases.append((scale, nScaleBits, nMantBits))
+            dq_in.append(mant)
+            dq_out.append(np.asarray(rq.vDequantize(scale, mant, nScaleBits, nMantBits), dtype=np.float64))
+d["dq_cases"], d["dq_in"], d["dq_out"] = np.array(dq_cases), np.array(dq_in), np.array(dq_out)
+du_bits = [2, 3, 8, 12, 16, 19, 24, 31]
+d["du_bits"] = np.array(du_bits)
+d["du_in"] = np.array([np.concatenate([[0, 1, (1 << (nb - 1)) - 1, 1 << (nb - 1), (1 << nb) - 1],
+                                       rng.integers(0, 1 << nb, 27)]) for nb in du_bits], dtype=np.float64)
+d["du_out"] = np.array([np.asarray(rq.vDequantizeUniform(row, nb), dtype=np.float64) for row, nb in zip(d["du_in"], du_bits)])
+for name, nl in (("long", LONG), ("short", SHORT), ("trans", TRANS)):
+    sfb = bands(nl)
+    n = int(np.sum(nl))
+    a1, a2 = rng.normal(0, 0.1, n), rng.normal(0, 0.1, n)
+    sw = rng.integers(0, 2, len(nl))
+    left, right = rm.ReconstructLR(a1, a2, sfb, sw)
+    d["lr_%s_in1" % name], d["lr_%s_in2" % name], d["lr_%s_sw" % name] = a1, a2, sw
+    d["lr_%s_left" % name], d["lr_%s_right" % name] = np.asarray(left, dtype=np.float64), np.asarray(right, dtype=np.float64)
+np.savez_compressed(os.path.join(OUT, "decode.npz"), **d)
+print("golden vectors written to", OUT)
