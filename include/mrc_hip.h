@@ -203,6 +203,44 @@ int mrc_dev_huffman_gain(mrc_handle* h, int a, int b, int64_t n_frames, int n_st
                          const int32_t* mantissa, const int32_t* reservoir_out, int32_t* huff_table,
                          int32_t* bits_saved, int32_t* reservoir_next, void* stream);
 
+/* ---- decode side ("next" row f-4: the reference's decoder, pacfileThem.py:130-585 + codecThem.py:30-134) ----
+ * Host: header and chunk parsing (no GPU, no handle).  Device: dequantise -> undo the overall scale -> M/S
+ * reconstruction -> IMDCT -> transition window -> overlap-and-add, and the 16-bit PCM codes. */
+
+/* pacfileThem.py:130-158.  Fills sample_rate, n_mdct_lines, n_scale_bits, n_mant_size_bits of *cfg (other fields
+ * untouched); data_offset = first chunk. */
+int mrc_pac_read_header(const uint8_t* buf, int64_t len, mrc_config* cfg, int32_t* n_channels, uint32_t* num_samples,
+                        int64_t* data_offset);
+/* Offsets of the `<L nBytes` + payload chunks after the header; returns their number (chunk_offset may be NULL /
+ * cap 0 to count), < 0 if a chunk is truncated. */
+int64_t mrc_pac_scan_chunks(const uint8_t* buf, int64_t len, int64_t data_offset, int64_t* chunk_offset, int64_t cap);
+/* The parsing half of PACFile.ReadDataBlock (pacfileThem.py:176-302, joint = 0) / JointReadDataBlock (341-560,
+ * joint = 1, two chunks per block): table id, block-switch bits -> (a, b), overall scale(s), M/S switch, band
+ * records with raw or Huffman-coded mantissas (prefix decoding by table; ids in sorted-name order).  Fixed strides
+ * because the shape varies from block to block: overall_scale [n][joint ? 4 : n_channels], ms_switch
+ * [n][MRC_MAX_BANDS], huff_table [n][n_channels], scale_factor / bit_alloc [n][n_channels][MRC_MAX_BANDS], mantissa
+ * [n][n_channels][n_mdct_lines] dense.  chunk_offset [n * n_channels]. */
+int mrc_unpack_blocks(const mrc_config* cfg, int64_t n_blocks, int n_channels, int joint, const uint8_t* buf, int64_t len,
+                      const int64_t* chunk_offset, int32_t* a, int32_t* b, int32_t* huff_table, int32_t* overall_scale,
+                      int32_t* ms_switch, int32_t* scale_factor, int32_t* bit_alloc, int32_t* mantissa);
+
+/* codecThem.Decode (30-63; n_streams = 1, overall_scale [n]) / JointDecode (65-134; n_streams = 2, overall_scale
+ * [n][4] = L,R,M,S, ms_switch [n][nBands]) for n blocks of shape (a, b): scale_factor / bit_alloc [n][n_streams][nBands],
+ * mantissa [n][n_streams][N/2] dense -> windowed blocks out [n][n_streams][a+b] (before overlap-and-add). */
+int mrc_decode(mrc_handle* h, int64_t n_blocks, int a, int b, int n_streams, const int32_t* overall_scale,
+               const int32_t* ms_switch, const int32_t* scale_factor, const int32_t* bit_alloc, const int32_t* mantissa,
+               double* out);
+/* Device form with the overlap-and-add of pacfileThem.py:312-315 fused: block i ADDS its a+b windowed samples to
+ * out_left (and out_right) starting at sample out_offset[i]; the caller zeroes the outputs first.  Every sample
+ * receives at most two contributions, so the sum does not depend on the order of the blocks. */
+int mrc_dev_decode(mrc_handle* h, int a, int b, int64_t n_blocks, int n_streams, const int32_t* overall_scale,
+                   const int32_t* ms_switch, const int32_t* scale_factor, const int32_t* bit_alloc,
+                   const int32_t* mantissa, const int64_t* out_offset, double* out_left, double* out_right, void* stream);
+/* pcmfile.py:163-172: signed fractions -> 16-bit PCM codes (sign-magnitude quantiser of quantize.py:61-87, then
+ * 2's complement).  mrc_pcm16: host pointers; mrc_dev_pcm16: device pointers. */
+int mrc_pcm16(mrc_handle* h, int64_t n, const double* x, int16_t* out);
+int mrc_dev_pcm16(mrc_handle* h, int64_t n, const double* x, int16_t* out, void* stream);
+
 /* Per-stage device time of the most recent mrc_dev_encode / stage call when timing is enabled
  * (hipEvents on the launch stream; the call then synchronises).  ms[0..2] = mdct, smr, alloc+quant. */
 int mrc_set_timing(mrc_handle* h, int enabled);

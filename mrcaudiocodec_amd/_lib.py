@@ -84,6 +84,14 @@ def _load():
                            [C.c_void_p] * 10),
         "mrc_huffman_gain": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p]),
         "mrc_dev_huffman_gain": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_int] + [C.c_void_p] * 7),
+        "mrc_pac_read_header": (C.c_int, [_u8p, C.c_int64, C.POINTER(MrcConfig), _i32p, C.POINTER(C.c_uint32), _i64p]),
+        "mrc_pac_scan_chunks": (C.c_int64, [_u8p, C.c_int64, C.c_int64, _i64p, C.c_int64]),
+        "mrc_unpack_blocks": (C.c_int, [C.POINTER(MrcConfig), C.c_int64, C.c_int, C.c_int, _u8p, C.c_int64, _i64p] +
+                              [_i32p] * 8),
+        "mrc_decode": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p, _i32p, _f64p]),
+        "mrc_dev_decode": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_int] + [C.c_void_p] * 9),
+        "mrc_pcm16": (C.c_int, [H, C.c_int64, _f64p, C.POINTER(C.c_int16)]),
+        "mrc_dev_pcm16": (C.c_int, [H, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
         "mrc_band_table": (C.c_int, [C.POINTER(MrcConfig), C.c_int, C.c_int, _i32p, _i32p]),
         "mrc_pack_bound": (C.c_int64, [C.POINTER(MrcConfig), C.c_int, C.c_int, C.c_int, C.c_int]),
         "mrc_pac_header": (C.c_int, [C.POINTER(MrcConfig), C.c_int, C.c_uint32, _u8p, C.c_int64, _i64p]),
@@ -284,6 +292,42 @@ class Handle:
                          reservoir_next=None, stream=None):
         self._check(lib.mrc_dev_huffman_gain(self._h, a, b, n_frames, n_streams, bit_alloc, mantissa, reservoir_out,
                                              huff_table, bits_saved, reservoir_next, stream))
+
+    # ---- decode side
+    def decode(self, a, b, overall_scale, scale_factor, bit_alloc, mantissa, ms_switch=None):
+        """codecThem.Decode / JointDecode for n blocks of shape (a,b): scale_factor / bit_alloc [n][nStreams][nBands],
+        mantissa [n][nStreams][N/2] dense, overall_scale [n] (mono) or [n][4] with ms_switch [n][nBands] (joint)
+        -> windowed blocks [n][nStreams][a+b] (before overlap-and-add)."""
+        sf, ba, m, osc = _i32(scale_factor), _i32(bit_alloc), _i32(mantissa), _i32(overall_scale)
+        n, ns = sf.shape[0], sf.shape[1]
+        nb, half = len(self.bands(a, b)), (a + b) // 2
+        if sf.shape != (n, ns, nb) or ba.shape != sf.shape or m.shape != (n, ns, half) or ns not in (1, 2):
+            raise ValueError("decode: array shapes do not match the block shape")
+        sw = None
+        if ns == 2:
+            sw = _i32(ms_switch)
+            if sw.shape != (n, nb) or osc.shape != (n, 4):
+                raise ValueError("decode: joint blocks need overall_scale [n][4] and ms_switch [n][nBands]")
+        elif osc.size != n:
+            raise ValueError("decode: overall_scale [n] expected")
+        out = np.empty((n, ns, a + b), np.float64)
+        self._check(lib.mrc_decode(self._h, n, int(a), int(b), ns, _p(osc, _i32p), _p(sw, _i32p), _p(sf, _i32p),
+                                   _p(ba, _i32p), _p(m, _i32p), _p(out, _f64p)))
+        return out
+
+    def pcm16(self, x):
+        x = _f64(x)
+        out = np.empty(x.shape, np.int16)
+        self._check(lib.mrc_pcm16(self._h, x.size, _p(x, _f64p), out.ctypes.data_as(C.POINTER(C.c_int16))))
+        return out
+
+    def dev_decode(self, a, b, n_blocks, n_streams, overall_scale, ms_switch, scale_factor, bit_alloc, mantissa,
+                   out_offset, out_left, out_right=None, stream=None):
+        self._check(lib.mrc_dev_decode(self._h, a, b, n_blocks, n_streams, overall_scale, ms_switch, scale_factor,
+                                       bit_alloc, mantissa, out_offset, out_left, out_right, stream))
+
+    def dev_pcm16(self, n, x, out, stream=None):
+        self._check(lib.mrc_dev_pcm16(self._h, n, x, out, stream))
 
     def transient_peaks(self, streams, sos):
         """streams [nCh][(nHops+1)*hop] -> peaks [nHops][nCh][hop/nShort + 1] (sub-block peaks, then the hop's peak)."""

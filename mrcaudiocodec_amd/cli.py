@@ -6,10 +6,15 @@ WAV ingest (pcmfile.py:34-102: 16-bit PCM, int16 code c -> sign(c) 2|c|/65535), 
 one hop of look-ahead (pacfileThem.py:1025-1056, 1182-1214), joint-stereo blocks with the bit reservoir
 chained through the Huffman savings, Close()'s flush block, `.pac` framing -- kernels on the GPU, Huffman
 and bit packing in C++ on the host.  Like the reference: stereo input only, and the last hop of the file is
-analysed but never encoded.  Decoding is out of scope.
+analysed but never encoded.
+
+Decode direction ("next" row f-4):  python -m mrcaudiocodec_amd.cli -d in.pac out.wav
+C++ chunk parser on the host, dequantise / M-S / IMDCT / window / overlap-add and the 16-bit PCM codes on the GPU,
+WAV header of pcmfile.py:141-153.  The first decoded block (the MDCT's half-block delay) is dropped as in the
+reference's loop; everything after it is written, header sample count = what was decoded.
 """
 import argparse
-from struct import unpack
+from struct import pack, unpack
 
 import numpy as np
 
@@ -68,15 +73,46 @@ def encode_wav(in_path, out_path=None, use_huffman=True, device_id=0, handle=Non
     return data
 
 
+def wav_bytes(pcm, sample_rate):
+    """pcmfile.py:141-153 header + interleaved little-endian int16 samples; pcm int16 [nCh][samples]."""
+    n_ch, n = pcm.shape
+    data = np.ascontiguousarray(pcm.T).astype("<i2").tobytes()
+    head = pack('<4sL4s4sLHHLLHH4sL', b"RIFF", 36 + len(data), b"WAVE", b"fmt ", 16, 1, n_ch, sample_rate,
+                sample_rate * n_ch * 2, n_ch * 2, 16, b"data", len(data))
+    return head + data
+
+
+def decode_pac_file(pac_path, wav_path, device_id=0):
+    with open(pac_path, "rb") as fp:
+        buf = fp.read()
+    cfg, _, _, _ = pacfile.read_header(buf)
+    h = Handle(sample_rate=cfg.sample_rate, n_mdct_lines=cfg.n_mdct_lines, n_scale_bits=cfg.n_scale_bits,
+               n_mant_size_bits=cfg.n_mant_size_bits, device_id=device_id)
+    try:
+        pcm = pacfile.decode_pac_pcm16(h, buf)
+    finally:
+        h.close()
+    data = wav_bytes(pcm, cfg.sample_rate)
+    with open(wav_path, "wb") as fp:
+        fp.write(data)
+    return pcm
+
+
 def main(argv=None):
-    ap = argparse.ArgumentParser(description="Encode a stereo 16-bit WAV to .pac on an MI355X")
-    ap.add_argument("wav")
-    ap.add_argument("pac")
+    ap = argparse.ArgumentParser(description="Encode a stereo 16-bit WAV to .pac (or, with -d, decode a .pac to WAV) "
+                                             "on an MI355X")
+    ap.add_argument("src")
+    ap.add_argument("dst")
+    ap.add_argument("-d", "--decode", action="store_true")
     ap.add_argument("--no-huffman", action="store_true")
     ap.add_argument("--device", type=int, default=0)
     a = ap.parse_args(argv)
-    data = encode_wav(a.wav, a.pac, not a.no_huffman, a.device)
-    print("%s: %d bytes" % (a.pac, len(data)))
+    if a.decode:
+        pcm = decode_pac_file(a.src, a.dst, a.device)
+        print("%s: %d channels x %d samples" % (a.dst, pcm.shape[0], pcm.shape[1]))
+        return
+    data = encode_wav(a.src, a.dst, not a.no_huffman, a.device)
+    print("%s: %d bytes" % (a.dst, len(data)))
 
 
 if __name__ == "__main__":

@@ -33,7 +33,7 @@ _handles = {}
 
 def _handle(cp):
     key = (int(cp.sampleRate), int(getattr(cp, "nMDCTLines", 1024)), int(getattr(cp, "nSamplesShort", 128)),
-           int(cp.nScaleBits), int(cp.nMantSizeBits), float(cp.targetBitsPerSample),
+           int(cp.nScaleBits), int(cp.nMantSizeBits), float(getattr(cp, "targetBitsPerSample", 2.86)),   # decode: unset
            int(getattr(cp, "blkswBitA", 0)), int(getattr(cp, "blkswBitB", 0)),
            int(getattr(cp, "deviceId", os.environ.get("MRC_DEVICE", 0))))
     if not isinstance(cp.sampleRate, (int, np.integer)):
@@ -166,6 +166,36 @@ def JointEncode(data, codingParams):
 # ------------------------------------------------------------------------------------------------ L1
 # The reference's helper functions keep their signatures; they carry no codingParams, so they run on a
 # default-parameter handle (48 kHz unless sampleRate is an argument).
+def _dense(mantissa, n_lines):
+    """The decoder's mantissa array (pacfileThem.py:221) holds N/2 or more entries, dense."""
+    half = int(np.sum(n_lines))
+    m = np.zeros(half, dtype=np.int32)
+    src = np.asarray(mantissa, dtype=np.int64)[:half]
+    m[:len(src)] = src
+    return m
+
+
+def Decode(scaleFactor, bitAlloc, mantissa, overallScaleFactor, codingParams):
+    """codecThem.py:30-63: one channel's windowed block of a+b samples (before overlap-and-add)."""
+    h = _handle(codingParams)
+    _, _, n_lines = _bands_checked(h, codingParams)
+    out = h.decode(codingParams.a, codingParams.b, [int(overallScaleFactor)], np.asarray(scaleFactor)[None, None, :],
+                   np.asarray(bitAlloc)[None, None, :], _dense(mantissa, n_lines)[None, None, :])
+    return out[0, 0]
+
+
+def JointDecode(scaleFactor, bitAlloc, mantissa, overallScaleFactor, codingParams, ms_switch):
+    """codecThem.py:65-134: [left, right] windowed blocks; overallScaleFactor = [L, R, M, S]."""
+    h = _handle(codingParams)
+    _, _, n_lines = _bands_checked(h, codingParams)
+    out = h.decode(codingParams.a, codingParams.b, np.asarray(overallScaleFactor, dtype=np.int32)[None, :],
+                   np.stack([np.asarray(scaleFactor[0]), np.asarray(scaleFactor[1])])[None],
+                   np.stack([np.asarray(bitAlloc[0]), np.asarray(bitAlloc[1])])[None],
+                   np.stack([_dense(mantissa[0], n_lines), _dense(mantissa[1], n_lines)])[None],
+                   np.asarray(ms_switch, dtype=np.int32)[None, :])
+    return [out[0, 0], out[0, 1]]
+
+
 def _default_handle(sampleRate=48000):
     class _P:
         pass

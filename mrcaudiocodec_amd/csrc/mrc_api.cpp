@@ -246,6 +246,26 @@ int mrc_dev_alloc_quant(mrc_handle* h, int a, int b, int64_t n_frames, int joint
     return MRC_OK;
 }
 
+int mrc_dev_decode(mrc_handle* h, int a, int b, int64_t n_blocks, int n_streams, const int32_t* overall_scale,
+                   const int32_t* ms_switch, const int32_t* scale_factor, const int32_t* bit_alloc,
+                   const int32_t* mantissa, const int64_t* out_offset, double* out_left, double* out_right, void* stream) {
+    if (!h || n_blocks < 0 || (n_streams != 1 && n_streams != 2) || !overall_scale || !scale_factor || !bit_alloc ||
+        !mantissa || !out_offset || !out_left || (n_streams == 2 && (!ms_switch || !out_right)))
+        return fail(h, MRC_ERR_INVALID, "mrc_dev_decode: bad argument");
+    const HostShape* hs;
+    int rc = get_shape(h, a, b, &hs);
+    if (rc) return rc;
+    MRC_HIP(h, launch_decode(hs->dev, n_blocks, n_streams, overall_scale, ms_switch, scale_factor, bit_alloc, mantissa,
+                             out_offset, out_left, out_right, pick_stream(h, stream)));
+    return MRC_OK;
+}
+
+int mrc_dev_pcm16(mrc_handle* h, int64_t n, const double* x, int16_t* out, void* stream) {
+    if (!h || n < 0 || !x || !out) return fail(h, MRC_ERR_INVALID, "mrc_dev_pcm16: bad argument");
+    MRC_HIP(h, launch_pcm16(n, x, out, pick_stream(h, stream)));
+    return MRC_OK;
+}
+
 int mrc_dev_huffman_gain(mrc_handle* h, int a, int b, int64_t n_frames, int n_streams, const int32_t* bit_alloc,
                          const int32_t* mantissa, const int32_t* reservoir_out, int32_t* huff_table,
                          int32_t* bits_saved, int32_t* reservoir_next, void* stream) {
@@ -499,6 +519,53 @@ int mrc_mantissa(mrc_handle* h, int64_t n, int n_scale_bits, const double* x, co
     MRC_HIP(h, launch_mantissa(n, n_scale_bits, h->inL.as<double>(), h->inAux.as<int>(), h->inAux2.as<int>(),
                                h->outC.as<int>(), h->stream));
     MRC_TRY(s.down(mant, h->outC, (size_t)n * sizeof(int32_t)));
+    MRC_HIP(h, hipStreamSynchronize(h->stream));
+    return MRC_OK;
+}
+
+int mrc_decode(mrc_handle* h, int64_t n, int a, int b, int n_streams, const int32_t* overall_scale,
+               const int32_t* ms_switch, const int32_t* scale_factor, const int32_t* bit_alloc, const int32_t* mantissa,
+               double* out) {
+    if (!h || n < 0 || (n_streams != 1 && n_streams != 2) || !overall_scale || !scale_factor || !bit_alloc || !mantissa ||
+        !out || (n_streams == 2 && !ms_switch))
+        return fail(h, MRC_ERR_INVALID, "mrc_decode: bad argument");
+    if (n == 0) return MRC_OK;
+    const HostShape* hs;
+    MRC_TRY(get_shape(h, a, b, &hs));
+    const DevShape& S = hs->dev;
+    MRC_HIP(h, hipSetDevice(h->device));
+    Staged s{h, h->stream};
+    const size_t nOs = n_streams == 2 ? 4 : 1;
+    const size_t szBand = (size_t)n * n_streams * S.nBands * sizeof(int32_t), szM = (size_t)n * n_streams * S.halfN * sizeof(int32_t);
+    const size_t szOut = (size_t)n * n_streams * S.N * sizeof(double);
+    MRC_TRY(s.up(h->inAux, overall_scale, (size_t)n * nOs * sizeof(int32_t)));
+    MRC_TRY(s.up(h->inAux2, scale_factor, szBand));
+    MRC_TRY(s.up(h->inAux3, bit_alloc, szBand));
+    MRC_TRY(s.up(h->inL, mantissa, szM));
+    if (n_streams == 2) MRC_TRY(s.up(h->inR, ms_switch, (size_t)n * S.nBands * sizeof(int32_t)));
+    // block i, channel c -> out[(i * n_streams + c) * N]: one plane, per-channel base pointers and a common offset
+    std::vector<int64_t> offs((size_t)n);
+    for (int64_t i = 0; i < n; ++i) offs[(size_t)i] = i * n_streams * (int64_t)S.N;
+    MRC_TRY(s.up(h->outA, offs.data(), (size_t)n * sizeof(int64_t)));
+    MRC_HIP(h, h->outG.reserve(szOut));
+    MRC_HIP(h, hipMemsetAsync(h->outG.p, 0, szOut, h->stream));
+    MRC_HIP(h, launch_decode(S, n, n_streams, h->inAux.as<int>(), n_streams == 2 ? h->inR.as<int>() : nullptr,
+                             h->inAux2.as<int>(), h->inAux3.as<int>(), h->inL.as<int>(), h->outA.as<int64_t>(),
+                             h->outG.as<double>(), h->outG.as<double>() + S.N, h->stream));
+    MRC_TRY(s.down(out, h->outG, szOut));
+    MRC_HIP(h, hipStreamSynchronize(h->stream));
+    return MRC_OK;
+}
+
+int mrc_pcm16(mrc_handle* h, int64_t n, const double* x, int16_t* out) {
+    if (!h || n < 0 || !x || !out) return fail(h, MRC_ERR_INVALID, "mrc_pcm16: bad argument");
+    if (n == 0) return MRC_OK;
+    MRC_HIP(h, hipSetDevice(h->device));
+    Staged s{h, h->stream};
+    MRC_TRY(s.up(h->inL, x, (size_t)n * sizeof(double)));
+    MRC_HIP(h, h->outA.reserve((size_t)n * sizeof(int16_t)));
+    MRC_HIP(h, launch_pcm16(n, h->inL.as<double>(), h->outA.as<short>(), h->stream));
+    MRC_TRY(s.down(out, h->outA, (size_t)n * sizeof(int16_t)));
     MRC_HIP(h, hipStreamSynchronize(h->stream));
     return MRC_OK;
 }

@@ -75,6 +75,11 @@ hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, con
                               int* bitAlloc, int* scaleFactor, int* mantissa, int* resOut, double* bandPeakWs,
                               hipStream_t st);
 size_t alloc_workspace_bytes(const DevShape& S, int64_t nFrames, int joint);   // bandPeakWs size
+// mrc_kernels_decode.hip
+hipError_t launch_decode(const DevShape& S, int64_t nBlocks, int nStreams, const int* oscale, const int* msSwitch,
+                         const int* scaleFactor, const int* bitAlloc, const int* mantissa, const int64_t* outOffset,
+                         double* outL, double* outR, hipStream_t st);
+hipError_t launch_pcm16(int64_t n, const double* x, short* out, hipStream_t st);
 // mrc_kernels_huff.hip
 hipError_t launch_huffman_gain(const DevShape& S, int64_t nFrames, int nStreams, const int* bitAlloc,
                                const int* mantissa, const int* reservoirOut, int* huffTable, int* bitsSaved,

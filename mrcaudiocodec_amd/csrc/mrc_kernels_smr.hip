@@ -68,35 +68,44 @@ __device__ __forceinline__ double exp2_poly(double f) {
     return fma(p, f, 1.0);
 }
 
-// 2^(s16*u/16) for the spreading loop, table driven: n = rint(s16*u) splits into k = n >> 4 (exponent),
-// j = n & 15 (entry of the 2^(j/16) table in LDS) and a remainder g = s16*u - n in [-1/2, 1/2] (exact, by
-// fma) whose 2^(g/16) is a degree-6 polynomial.  13 fp64 + 4 integer instructions per pair instead of 19 + 1;
-// max relative error ~3e-16.  s16*u == 0 gives exactly 1 (a line inside +-1/2 Bark gets exactly the masker's
-// intensity).  Requires |s16*u| < 2^20 (here it is < 4000): the exponent field of v cannot leave the normal range.
-__device__ __forceinline__ double exp2_tab16(double s16, double u, const double* __restrict__ tab) {
+// 2^(s64*u/64) for the spreading loop, table driven: n = rint(s64*u) splits into k = n >> 6 (exponent),
+// j = n & 63 (entry of the 2^(j/64) table in LDS) and a remainder g = s64*u - n in [-1/2, 1/2] (exact, by fma)
+// whose 2^(g/64) = exp(g ln2/64) is the Taylor polynomial of degree 5 (remainder < 3.5e-17).  10 fp64 + 4 integer
+// instructions per pair; max relative error ~3e-16.  s64*u == 0 gives exactly 1 (a line inside +-1/2 Bark gets
+// exactly the masker's intensity).  Requires |s64*u| < 2^31 (here it is < 16000).
+constexpr int kExpTab = 64;
+__device__ __forceinline__ double exp2_tab64(double s64, double u, const double* __restrict__ tab) {
     const double shifter = 0x1.8p52;
-    const double tt = fma(s16, u, shifter);
+    const double tt = fma(s64, u, shifter);
     const double r = tt - shifter;
-    const double g = fma(s16, u, -r);
+    const double g = fma(s64, u, -r);
     const int n = __double2loint(tt);
-    double p = 0x1.430a49610efc6p-13 * 0x1p-24;          // coefficients of 2^f pre-divided by 16^j (f = g/16)
-    p = fma(p, g, 0x1.5d89be4c12513p-10 * 0x1p-20);
-    p = fma(p, g, 0x1.3b2ab6fb09b31p-7 * 0x1p-16);
-    p = fma(p, g, 0x1.c6b08d6e8a384p-5 * 0x1p-12);
-    p = fma(p, g, 0x1.ebfbdff82c594p-3 * 0x1p-8);
-    p = fma(p, g, 0x1.62e42fefa39fdp-1 * 0x1p-4);
+    double p = fma(0x1.5d87fe78a6731p-40, g, 0x1.3b2ab6fba4e77p-31);
+    p = fma(p, g, 0x1.c6b08d704a0c0p-23);
+    p = fma(p, g, 0x1.ebfbdff82c58fp-15);
+    p = fma(p, g, 0x1.62e42fefa39efp-7);
     p = fma(p, g, 1.0);
-    const double v = p * tab[n & 15];
-    const int hi = __double2hiint(v) + ((n >> 4) << 20);
-    return __hiloint2double(hi, __double2loint(v));
+    return ldexp(p * tab[n & (kExpTab - 1)], n >> 6);
 }
 
-// 2^(j/16), j = 0..15, correctly rounded
-__constant__ double kExp2Sixteenths[16] = {
-    0x1.0000000000000p+0, 0x1.0b5586cf9890fp+0, 0x1.172b83c7d517bp+0, 0x1.2387a6e756238p+0,
-    0x1.306fe0a31b715p+0, 0x1.3dea64c123422p+0, 0x1.4bfdad5362a27p+0, 0x1.5ab07dd485429p+0,
-    0x1.6a09e667f3bcdp+0, 0x1.7a11473eb0187p+0, 0x1.8ace5422aa0dbp+0, 0x1.9c49182a3f090p+0,
-    0x1.ae89f995ad3adp+0, 0x1.c199bdd85529cp+0, 0x1.d5818dcfba487p+0, 0x1.ea4afa2a490dap+0};
+// 2^(j/64), j = 0..63, correctly rounded
+__constant__ double kExp2Tab[kExpTab] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
 
 // 2^(hi + lo), |lo| << 1
 __device__ __forceinline__ double exp2_dd(double hi, double lo) {
@@ -212,7 +221,6 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                                                        double* __restrict__ thresh, SmrLds lay) {
     extern __shared__ double smem[];
     __shared__ int waveCnt[kThreads / kWave];
-    __shared__ double e2tab[16];                        // 2^(j/16)
     __shared__ unsigned long long bandKey[kMaxBands];   // per-band running max of the excess (order-preserving key)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6;
@@ -234,8 +242,8 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     long long tPhase_ = clock64();
 #endif
     if (tid < kMaxBands) bandKey[tid] = 0ull;           // below every key; visible after the first barrier
-    if (tid < 16) e2tab[tid] = kExp2Sixteenths[tid];
     const double* zbS = smem + lay.zbOff;               // staged after the FFT (the area is FFT scratch / dead)
+    const double* e2tab = smem + 2 * H - kExpTab;       // 2^(j/64): the tail of region A, behind the masker table
     const double* logTab = smem + lay.logOff;
     // Hann window (window.py:28-45) and real FFT through an H = N/2 point complex FFT.  All global loads of a
     // thread are issued before the first use: one memory round trip per phase instead of one per iteration.
@@ -296,6 +304,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
         double* zw = smem + lay.zbOff;
         for (int k = tid; k < M; k += kThreads) zw[k] = S.zb[k];
         if (tid < kLogTabEntries * 4) smem[lay.logOff + tid] = kLogTabDev.v[tid];
+        if (tid < kExpTab) smem[2 * H - kExpTab + tid] = kExp2Tab[tid];
     }
 
     // tonal maskers: strict 3-point peaks at bins p = 1 .. last-2, kept in increasing bin order.
@@ -351,7 +360,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                 const double ph = kLowHi * zm;
                 const double pl = fma(kLowHi, zm, -ph) + kLowLo * zm;
                 e[0] = I;
-                e[2] = (((-27 + boost) / 10) * kLog2Of10) * 16.0;          // upper slope, 1/16 bit per Bark
+                e[2] = (((-27 + boost) / 10) * kLog2Of10) * 64.0;          // upper slope, 1/64 bit per Bark
                 e[3] = I * exp2_dd(ph, pl);
                 // first line that sees this masker at all (fl(z_k - z_m) >= -1/2) and first line more than
                 // 1/2 Bark above it (fl(z_k - z_m) > 1/2): both predicates are monotone in k
@@ -561,8 +570,8 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                         for (int j = 0; j <= kFarOrder; ++j) B[j] = 0.0;
                         for (int m = lane; m < nFar; m += kWave) {
                             const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
-                            double term = I * exp2_tab16(sl, cq - zm, e2tab);          // cq - zm > 0 for m < nFar
-                            const double a = sl * (0.6931471805599453094 / 16.0);     // slope in nats per Bark
+                            double term = I * exp2_tab64(sl, cq - zm, e2tab);          // cq - zm > 0 for m < nFar
+                            const double a = sl * (0.6931471805599453094 / 64.0);     // slope in nats per Bark
 #pragma unroll
                             for (int j = 0; j <= kFarOrder; ++j) {
                                 B[j] += term;
@@ -583,19 +592,29 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                 }
             }
             MRC_PHASE(7);
-            // some line of the chunk is above the masker's band, every line sees the masker
+            // some line of the chunk is above the masker's band, every line sees the masker.  Maskers below
+            // nUp of the chunk's FIRST line are more than 1/2 Bark below every line: u > 0 without the clamp.
+            {
+                const int mPos = min(max(__builtin_amdgcn_readfirstlane(nUp), mFirst), mPlain);
+                const int mStop = (MRC_PROFILE_SKIP & 2) ? 0 : mPlain;
 #pragma unroll 4
-            for (int m = mFirst; m < ((MRC_PROFILE_SKIP & 2) ? 0 : mPlain); ++m) {
-                const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
-                const double u = fmax(zq - zm, 0.0);
-                tot = fma(I, exp2_tab16(sl, u, e2tab), tot);
+                for (int m = mFirst; m < min(mPos, mStop); ++m) {
+                    const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
+                    tot = fma(I, exp2_tab64(sl, zq - zm, e2tab), tot);
+                }
+#pragma unroll 4
+                for (int m = mPos; m < mStop; ++m) {
+                    const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
+                    const double u = fmax(zq - zm, 0.0);
+                    tot = fma(I, exp2_tab64(sl, u, e2tab), tot);
+                }
             }
             MRC_PHASE(8);
             // same, but part of the chunk lies below the masker's band (only when the chunk spans > 1 Bark)
             for (int m = mPlain; m < ((MRC_PROFILE_SKIP & 4) ? 0 : mExp); ++m) {
                 const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
                 const double u = fmax(zq - zm, 0.0);
-                tot = fma(m < cnt ? I : 0.0, exp2_tab16(sl, u, e2tab), tot);
+                tot = fma(m < cnt ? I : 0.0, exp2_tab64(sl, u, e2tab), tot);
             }
             MRC_PHASE(9);
             // no line of the chunk is above the band: every line that sees the masker is inside +-1/2 Bark

@@ -170,6 +170,82 @@ bool shape_ok(const mrc_config* cfg, int a, int b) {
            cfg->n_scale_bits <= 4 && cfg->n_mant_size_bits >= 1 && cfg->n_mant_size_bits <= 8;
 }
 
+
+// ---- decode side ("next" row f-4): chunk parser -----------------------------------------------------------
+// Huffman codes are at most 9 bits long: a 512-entry table per code maps the next 9 bits to (value, length).
+constexpr int kPeekBits = 9;
+struct DecLut {
+    short value[4][1 << kPeekBits];
+    unsigned char len[4][1 << kPeekBits];
+    DecLut() {
+        std::memset(len, 0, sizeof(len));
+        std::memset(value, 0, sizeof(value));
+        for (int t = 0; t < 4; ++t)
+            for (int i = 0; i < kTables[t].nCodes; ++i) {
+                const int v = kTables[t].codes[i].value, n = kLut.len[t][v];
+                const unsigned head = (unsigned)kLut.bits[t][v] << (kPeekBits - n);
+                for (unsigned tail = 0; tail < (1u << (kPeekBits - n)); ++tail) {
+                    value[t][head | tail] = (short)v;
+                    len[t][head | tail] = (unsigned char)n;
+                }
+            }
+    }
+};
+const DecLut kDecLut;
+
+// MSB-first reader (bitpack.py:104-170); reading past the end flags an error and returns zeros
+struct BitReader {
+    const uint8_t* p;
+    int64_t nBits, pos = 0;
+    bool ok = true;
+    BitReader(const uint8_t* data, int64_t nBytes) : p(data), nBits(nBytes * 8) {}
+    unsigned peek(int n) const {                       // n <= 25; bits past the end read as zero
+        uint64_t w = 0;
+        const int64_t byte = pos >> 3;
+        for (int i = 0; i < 5; ++i) w = (w << 8) | ((byte + i) * 8 < nBits ? p[byte + i] : 0u);
+        return (unsigned)((w >> (40 - (pos & 7) - n)) & ((1u << n) - 1u));
+    }
+    unsigned get(int n) {
+        if (n <= 0) return 0;
+        if (pos + n > nBits) { ok = false; pos = nBits; return 0; }
+        const unsigned v = peek(n);
+        pos += n;
+        return v;
+    }
+};
+
+// pacfileThem.py:219-302: per band {ba-1 | 0 : nMantSizeBits, scale factor : nScaleBits, mantissas : ba bits each or
+// Huffman codes (+ ba raw bits after the escape code)}; mantissas land at the band's own lines (dense)
+bool read_band_records(BitReader& r, const mrc_config& cfg, int table, const std::vector<int>& bandN, int32_t* sf,
+                       int32_t* ba, int32_t* mant) {
+    int line = 0;
+    for (size_t band = 0; band < bandN.size(); ++band) {
+        int bits = (int)r.get(cfg.n_mant_size_bits);
+        if (bits) ++bits;
+        ba[band] = bits;
+        sf[band] = (int32_t)r.get(cfg.n_scale_bits);
+        if (bits) {
+            for (int j = 0; j < bandN[band]; ++j) {
+                if (table == kRawTable) {
+                    mant[line + j] = (int32_t)r.get(bits);
+                } else {
+                    const unsigned w = r.peek(kPeekBits);
+                    const int n = kDecLut.len[table][w];
+                    if (!n) return false;
+                    r.get(n);
+                    const int v = kDecLut.value[table][w];
+                    mant[line + j] = (v == kTables[table].escape) ? (int32_t)r.get(bits) : v;
+                }
+            }
+        }
+        line += bandN[band];
+    }
+    return r.ok;
+}
+
+inline uint32_t get_u32le(const uint8_t* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+inline uint32_t get_u16le(const uint8_t* p) { return p[0] | (p[1] << 8); }
+
 }  // namespace
 
 extern "C" {
@@ -305,6 +381,84 @@ int mrc_pack_joint_blocks(const mrc_config* cfg, int64_t n_blocks, int a, int b,
                           int64_t* block_offset, int32_t* huff_table, int32_t* bits_saved) {
     return pack_blocks(cfg, n_blocks, 2, a, b, 1, use_huffman, overall_scale, ms_switch, scale_factor, bit_alloc,
                        mantissa, out, out_cap, block_offset, huff_table, bits_saved);
+}
+
+
+// ---- decode side ---------------------------------------------------------------------------------------------
+int mrc_pac_read_header(const uint8_t* buf, int64_t len, mrc_config* cfg, int32_t* n_channels, uint32_t* num_samples,
+                        int64_t* data_offset) {
+    if (!buf || !cfg || !n_channels || !num_samples || !data_offset || len < 26) return MRC_ERR_INVALID;
+    if (std::memcmp(buf, "PAC ", 4) != 0) return MRC_ERR_INVALID;
+    cfg->sample_rate = (int32_t)get_u32le(buf + 4);
+    *n_channels = (int32_t)get_u16le(buf + 8);
+    *num_samples = get_u32le(buf + 10);
+    cfg->n_mdct_lines = (int32_t)get_u32le(buf + 14);
+    cfg->n_scale_bits = (int32_t)get_u16le(buf + 18);
+    cfg->n_mant_size_bits = (int32_t)get_u16le(buf + 20);
+    const uint32_t nBands = get_u32le(buf + 22);
+    if (nBands > 4096 || 26 + 2 * (int64_t)nBands > len) return MRC_ERR_INVALID;
+    *data_offset = 26 + 2 * (int64_t)nBands;           // the band table itself is implied by rate and block length
+    return MRC_OK;
+}
+
+int64_t mrc_pac_scan_chunks(const uint8_t* buf, int64_t len, int64_t data_offset, int64_t* chunk_offset, int64_t cap) {
+    if (!buf || data_offset < 0 || data_offset > len) return MRC_ERR_INVALID;
+    int64_t n = 0, off = data_offset;
+    while (off + 4 <= len) {
+        const int64_t nBytes = get_u32le(buf + off);
+        if (off + 4 + nBytes > len) return MRC_ERR_INVALID;        // truncated chunk
+        if (chunk_offset && n < cap) chunk_offset[n] = off;
+        ++n;
+        off += 4 + nBytes;
+    }
+    return n;
+}
+
+int mrc_unpack_blocks(const mrc_config* cfg, int64_t n_blocks, int n_channels, int joint, const uint8_t* buf, int64_t len,
+                      const int64_t* chunk_offset, int32_t* a_out, int32_t* b_out, int32_t* huff_table,
+                      int32_t* overall_scale, int32_t* ms_switch, int32_t* scale_factor, int32_t* bit_alloc,
+                      int32_t* mantissa) {
+    if (!cfg || !buf || !chunk_offset || !a_out || !b_out || !huff_table || !overall_scale || !scale_factor ||
+        !bit_alloc || !mantissa || n_blocks < 0 || n_channels < 1 || n_channels > 2 || (joint && (n_channels != 2 || !ms_switch)) ||
+        !shape_ok(cfg, cfg->n_mdct_lines, cfg->n_mdct_lines))
+        return MRC_ERR_INVALID;
+    const int L = cfg->n_mdct_lines, nOs = joint ? 4 : n_channels;
+    std::atomic<int> bad{0};
+    parallel_for(n_blocks, [&](int64_t blk) {
+        std::vector<int> bandN;
+        for (int ch = 0; ch < n_channels; ++ch) {
+            const int64_t off = chunk_offset[blk * n_channels + ch];
+            if (off < 0 || off + 4 > len) { bad = 1; return; }
+            const int64_t nBytes = get_u32le(buf + off);
+            if (off + 4 + nBytes > len) { bad = 1; return; }
+            BitReader r(buf + off + 4, nBytes);
+            const int table = (int)r.get(4);
+            if (table != kRawTable && table > 3) { bad = 1; return; }
+            const int swA = (int)r.get(cfg->blksw_bits_a), swB = (int)r.get(cfg->blksw_bits_b);
+            const int a = swA ? cfg->n_short : L, b = swB ? cfg->n_short : L;      // pacfileThem.py:206-207
+            if (ch == 0) { a_out[blk] = a; b_out[blk] = b; }
+            else if (a != a_out[blk] || b != b_out[blk]) { bad = 1; return; }
+            if (!mrc::band_table(*cfg, a, b, &bandN) || (int)bandN.size() > MRC_MAX_BANDS) { bad = 1; return; }
+            huff_table[blk * n_channels + ch] = table;
+            if (joint) {
+                if (ch == 0) {
+                    for (int i = 0; i < 4; ++i) overall_scale[blk * 4 + i] = (int32_t)r.get(cfg->n_scale_bits);
+                    for (int i = 0; i < MRC_MAX_BANDS; ++i)
+                        ms_switch[blk * MRC_MAX_BANDS + i] = i < (int)bandN.size() ? (int32_t)r.get(1) : 0;
+                }
+            } else {
+                overall_scale[blk * nOs + ch] = (int32_t)r.get(cfg->n_scale_bits);
+            }
+            int32_t* sf = scale_factor + (blk * n_channels + ch) * MRC_MAX_BANDS;
+            int32_t* ba = bit_alloc + (blk * n_channels + ch) * MRC_MAX_BANDS;
+            int32_t* m = mantissa + (blk * n_channels + ch) * (int64_t)L;
+            std::memset(sf, 0, sizeof(int32_t) * MRC_MAX_BANDS);
+            std::memset(ba, 0, sizeof(int32_t) * MRC_MAX_BANDS);
+            std::memset(m, 0, sizeof(int32_t) * L);
+            if (!read_band_records(r, *cfg, table, bandN, sf, ba, m)) { bad = 1; return; }
+        }
+    });
+    return bad.load() ? MRC_ERR_INVALID : MRC_OK;
 }
 
 }  // extern "C"

@@ -185,3 +185,115 @@ def encode_stereo_streams(handle, streams, shapes, use_huffman=True, num_samples
         for s in range(nS):
             parts[s].append(data[offs[s]:offs[s + 1]].tobytes())
     return [b"".join(p) for p in parts]
+
+
+# ------------------------------------------------------------------ decode side ("next" row f-4)
+def read_header(buf):
+    """pacfileThem.py:130-158 -> (cfg with the file's parameters, nChannels, numSamples, offset of the first chunk)."""
+    raw = np.frombuffer(buf, dtype=np.uint8)
+    cfg = make_config()
+    nch, ns, off = C.c_int32(), C.c_uint32(), C.c_int64()
+    _check(lib.mrc_pac_read_header(raw.ctypes.data_as(_u8p), raw.size, C.byref(cfg), C.byref(nch), C.byref(ns),
+                                   C.byref(off)), "mrc_pac_read_header")
+    return cfg, nch.value, ns.value, off.value
+
+
+def scan_chunks(buf, data_offset):
+    raw = np.frombuffer(buf, dtype=np.uint8)
+    n = lib.mrc_pac_scan_chunks(raw.ctypes.data_as(_u8p), raw.size, int(data_offset), None, 0)
+    if n < 0:
+        raise MrcError("truncated .pac chunk")
+    offs = np.zeros(max(n, 1), dtype=np.int64)
+    lib.mrc_pac_scan_chunks(raw.ctypes.data_as(_u8p), raw.size, int(data_offset), offs.ctypes.data_as(_i64p), n)
+    return offs[:n]
+
+
+def unpack_blocks(cfg, buf, chunk_offsets, n_channels, joint):
+    """The parsing half of (Joint)ReadDataBlock for the blocks whose chunks start at chunk_offsets
+    [n * n_channels] -> dict of fixed-stride arrays (see mrc_unpack_blocks)."""
+    raw = np.frombuffer(buf, dtype=np.uint8)
+    offs = np.ascontiguousarray(chunk_offsets, dtype=np.int64)
+    n = offs.size // n_channels
+    L, B = cfg.n_mdct_lines, _lib.MRC_MAX_BANDS
+    out = dict(a=np.zeros(n, np.int32), b=np.zeros(n, np.int32), huff_table=np.zeros((n, n_channels), np.int32),
+               overall_scale=np.zeros((n, 4 if joint else n_channels), np.int32), ms_switch=np.zeros((n, B), np.int32),
+               scale_factor=np.zeros((n, n_channels, B), np.int32), bit_alloc=np.zeros((n, n_channels, B), np.int32),
+               mantissa=np.zeros((n, n_channels, L), np.int32))
+    p = lambda k: out[k].ctypes.data_as(_i32p)
+    _check(lib.mrc_unpack_blocks(C.byref(cfg), n, n_channels, int(bool(joint)), raw.ctypes.data_as(_u8p), raw.size,
+                                 offs.ctypes.data_as(_i64p), p("a"), p("b"), p("huff_table"), p("overall_scale"),
+                                 p("ms_switch"), p("scale_factor"), p("bit_alloc"), p("mantissa")), "mrc_unpack_blocks")
+    return out
+
+
+def decode_pac(handle, buf):
+    """Decode a whole `.pac` byte string on the GPU of `handle` (which must have been created with the file's
+    parameters): C++ chunk parser on the host, then per block shape one launch of the fused dequantise / M-S /
+    IMDCT / window / overlap-add kernel into a device-resident output stream.  Returns (nChannels, float64
+    [nCh][samples]): the concatenation of what the reference's successive (Joint)ReadDataBlock calls return --
+    out[:, :L] is the half-block delay of the MDCT, the signal follows.  A stereo file is joint blocks followed by
+    the two non-joint chunks Close() wrote (pacfileThem.py:973-984)."""
+    import torch
+    cfg, nch, _, off = read_header(buf)
+    c = handle.cfg
+    for k in ("sample_rate", "n_mdct_lines", "n_scale_bits", "n_mant_size_bits"):
+        if getattr(cfg, k) != getattr(c, k):
+            raise ValueError("handle was created with %s = %d, the file has %d" % (k, getattr(c, k), getattr(cfg, k)))
+    cfg.n_short, cfg.blksw_bits_a, cfg.blksw_bits_b = c.n_short, c.blksw_bits_a, c.blksw_bits_b
+    chunks = scan_chunks(buf, off)
+    if nch not in (1, 2) or len(chunks) % nch:
+        raise ValueError("unsupported channel count / chunk count")
+    n_blocks = len(chunks) // nch
+    groups = []                                              # (joint, parsed blocks) in file order
+    if nch == 2 and n_blocks > 1:
+        groups.append((True, unpack_blocks(cfg, buf, chunks[:2 * (n_blocks - 1)], 2, True)))
+        groups.append((False, unpack_blocks(cfg, buf, chunks[2 * (n_blocks - 1):], 2, False)))
+    else:
+        groups.append((False, unpack_blocks(cfg, buf, chunks, nch, False)))
+    a_all = np.concatenate([g["a"] for _, g in groups])
+    b_all = np.concatenate([g["b"] for _, g in groups])
+    starts = np.concatenate([[0], np.cumsum(a_all)[:-1]]).astype(np.int64)      # block i adds to [start, start + a + b)
+    total = int(starts[-1] + a_all[-1] + b_all[-1]) if n_blocks else 0
+    dev = torch.device("cuda", c.device_id)
+    out = torch.zeros((nch, total), dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    keep = []                                                # device inputs stay alive until the sync
+    base = 0
+    for joint, g in groups:
+        n = len(g["a"])
+        shapes = sorted(set(zip(g["a"].tolist(), g["b"].tolist())))
+        for (a, b) in shapes:
+            idx = np.nonzero((g["a"] == a) & (g["b"] == b))[0]
+            nb, half = len(handle.bands(a, b)), (a + b) // 2
+            offs = torch.from_numpy(starts[base + idx]).to(dev)
+            up = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+            if joint:
+                args = (up(g["overall_scale"][idx]), up(g["ms_switch"][idx, :nb]), up(g["scale_factor"][idx][:, :, :nb]),
+                        up(g["bit_alloc"][idx][:, :, :nb]), up(g["mantissa"][idx][:, :, :half]))
+                handle.dev_decode(a, b, len(idx), 2, args[0].data_ptr(), args[1].data_ptr(), args[2].data_ptr(),
+                                  args[3].data_ptr(), args[4].data_ptr(), offs.data_ptr(), out[0].data_ptr(),
+                                  out[1].data_ptr(), stream)
+                keep.append((args, offs))
+            else:
+                for ch in range(nch):                        # independent channels: one mono launch per channel
+                    args = (up(g["overall_scale"][idx, ch]), up(g["scale_factor"][idx, ch, :nb][:, None, :]),
+                            up(g["bit_alloc"][idx, ch, :nb][:, None, :]), up(g["mantissa"][idx, ch, :half][:, None, :]))
+                    handle.dev_decode(a, b, len(idx), 1, args[0].data_ptr(), None, args[1].data_ptr(),
+                                      args[2].data_ptr(), args[3].data_ptr(), offs.data_ptr(), out[ch].data_ptr(), None,
+                                      stream)
+                    keep.append((args, offs))
+        base += n
+    torch.cuda.synchronize(dev)
+    return nch, out
+
+
+def decode_pac_pcm16(handle, buf):
+    """decode_pac + the 16-bit PCM codes of pcmfile.py:163-172, with the first block (the MDCT's half-block delay)
+    dropped as the reference's decode loop does (pacfileThem.py:1176-1179).  -> int16 [nCh][samples] (host)."""
+    import torch
+    nch, x = decode_pac(handle, buf)
+    L = handle.cfg.n_mdct_lines
+    x = x[:, L:].contiguous()
+    pcm = torch.empty(x.shape, dtype=torch.int16, device=x.device)
+    handle.dev_pcm16(x.numel(), x.data_ptr(), pcm.data_ptr(), torch.cuda.current_stream(x.device).cuda_stream)
+    return pcm.cpu().numpy()

@@ -1,0 +1,70 @@
+"""
+CPU tests of the decode-side host code: the C++ `.pac` header / chunk parser (mrc_pac_read_header,
+mrc_pac_scan_chunks, mrc_unpack_blocks; no GPU needed) against the oracle's restatement of the reference's reader
+(oracle/decode.py), on streams the oracle's writer produced -- raw and Huffman-coded, with block switching.
+"""
+import numpy as np
+import pytest
+
+from mrcaudiocodec_amd import pacfile as ppac, synth
+from oracle import decode as odec, pacfile as opac
+
+
+def _stream(hops, switched):
+    tone = synth.c1_sine(hops)
+    if switched:
+        x, shapes = synth.c4_transients(hops)
+        return np.stack([x + 0.3 * tone, 0.7 * x + 0.3 * tone]), shapes
+    g = synth.c2_noise(hops, seed=5, sigma=0.02)
+    return np.stack([tone + g, 0.9 * tone - g]), [(i * 1024, 1024, 1024) for i in range(hops - 1)]
+
+
+@pytest.mark.parametrize("huff", [False, True])
+@pytest.mark.parametrize("switched", [False, True])
+def test_unpack_matches_oracle_reader(huff, switched):
+    stream, shapes = _stream(11 if switched else 6, switched)
+    pac = opac.encode_stereo_stream(stream, shapes, huffman=huff)
+    cfg, nch, num_samples, off = ppac.read_header(pac)
+    cp, off_ref = odec.read_header(pac)
+    assert (cfg.sample_rate, cfg.n_mdct_lines, cfg.n_scale_bits, cfg.n_mant_size_bits, nch, num_samples, off) == \
+           (cp.sampleRate, cp.nMDCTLines, cp.nScaleBits, cp.nMantSizeBits, cp.nChannels, cp.numSamples, off_ref)
+    chunks = ppac.scan_chunks(pac, off)
+    ref_chunks = odec.split_chunks(pac, off_ref)
+    assert len(chunks) == len(ref_chunks) == 2 * (len(shapes) + 1)
+    n_joint = len(shapes)
+    got = ppac.unpack_blocks(cfg, pac, chunks[:2 * n_joint], 2, True)
+    for i, (_, a, b) in enumerate(shapes):
+        want = odec.parse_joint_block(ref_chunks[2 * i], ref_chunks[2 * i + 1], cp)
+        nb, half = cp.sfBands.nBands, (a + b) // 2
+        assert (got["a"][i], got["b"][i]) == (a, b) == (cp.a, cp.b)
+        assert list(got["huff_table"][i]) == want["huffTable"]
+        assert list(got["overall_scale"][i]) == want["overallScale"]
+        assert list(got["ms_switch"][i, :nb]) == want["ms_switch"] and not got["ms_switch"][i, nb:].any()
+        for ch in range(2):
+            assert list(got["scale_factor"][i, ch, :nb]) == want["scaleFactor"][ch]
+            assert list(got["bit_alloc"][i, ch, :nb]) == want["bitAlloc"][ch]
+            assert np.array_equal(got["mantissa"][i, ch, :half], want["mantissa"][ch][:half])
+    if huff and not switched:
+        assert (got["huff_table"] != 15).any()              # the Huffman branch is exercised
+    flush = ppac.unpack_blocks(cfg, pac, chunks[2 * n_joint:], 2, False)
+    for ch in range(2):
+        want = odec.parse_block(ref_chunks[2 * n_joint + ch], cp)
+        nb = cp.sfBands.nBands
+        assert flush["overall_scale"][0, ch] == want["overallScale"] and flush["huff_table"][0, ch] == want["huffTable"]
+        assert list(flush["bit_alloc"][0, ch, :nb]) == want["bitAlloc"]
+        assert np.array_equal(flush["mantissa"][0, ch], want["mantissa"])
+
+
+def test_unpack_rejects_damaged_input():
+    stream, shapes = _stream(4, False)
+    pac = opac.encode_stereo_stream(stream, shapes, huffman=True)
+    cfg, nch, _, off = ppac.read_header(pac)
+    with pytest.raises(ppac.MrcError):
+        ppac.read_header(b"RIFF" + pac[4:])
+    with pytest.raises(ppac.MrcError):
+        ppac.scan_chunks(pac[:-3], off)                     # last chunk truncated
+    chunks = ppac.scan_chunks(pac, off)
+    bad = bytearray(pac)
+    bad[chunks[0] + 4] = 0x4F                                # table id 4: not a table, not raw
+    with pytest.raises(ppac.MrcError):
+        ppac.unpack_blocks(cfg, bytes(bad), chunks[:2], 2, True)

@@ -99,3 +99,48 @@ if __name__ == "__main__":
         print(N, "rfft err", e)
         assert e < 1e-11
     print("ok")
+
+
+def imdct_n4(X, a, b):
+    """Inverse with the reference's phase (mdct.py:98-122): x[n] = sum_k 2 X[k] cos(2pi/N (n+(b+1)/2)(k+1/2)).
+    DCT-IV of the lines through the same N/4-point FFT as the forward transform, then the transpose of the fold
+    (unfold M -> N) and the inverse of the signed circular shift."""
+    N = a + b
+    M = N // 2
+    Q = N // 4
+    h = Q
+    d = (b - a) // 4
+    n = np.arange(Q)
+    t = (X[2 * n] + 1j * X[M - 1 - 2 * n]) * np.exp(-1j * np.pi * (4 * n + 1) / (4 * M))
+    c = np.fft.fft(t) * np.exp(-1j * np.pi * (4 * n) / (4 * M))
+    v = np.empty(M)
+    v[2 * n] = c.real
+    v[M - 1 - 2 * n] = -c.imag                       # v = DCT-IV(X)
+    y = np.empty(N)
+    for i in range(h):
+        y[3 * h - 1 - i] = -v[i]
+        y[3 * h + i] = -v[i]
+        y[i] = v[h + i]
+        y[2 * h - 1 - i] = -v[h + i]
+    x = np.empty(N)
+    for i in range(N):
+        m = i + d
+        if m < 0:
+            x[i] = -y[m + N]
+        elif m >= N:
+            x[i] = -y[m - N]
+        else:
+            x[i] = y[m]
+    return 2.0 * x
+
+
+if __name__ == "__main__":
+    rng = np.random.default_rng(0)
+    for (a, b) in [(1024, 1024), (128, 128), (1024, 128), (128, 1024), (4, 4)]:
+        N = a + b
+        X = rng.normal(size=N // 2)
+        n0 = (b + 1) / 2
+        k = np.arange(N // 2)
+        ref = np.array([np.sum(2.0 * X * np.cos(2 * np.pi / N * (i + n0) * (k + 0.5))) for i in range(N)])
+        got = imdct_n4(X, a, b)
+        print("imdct", (a, b), np.max(np.abs(got - ref)) / np.max(np.abs(ref)))
