@@ -38,14 +38,20 @@ __device__ __forceinline__ double order_value(unsigned long long k) {
     unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
     return __longlong_as_double((long long)b);
 }
-// far-field local expansion (see the sweep): order, widest group of lines (Bark), fewest maskers worth it
-constexpr int kFarOrder = 16;
-constexpr double kFarSpan = 0.225;
-constexpr int kFarMinMaskers = 48;
-constexpr double kInvFactorial[kFarOrder + 1] = {
+// far-field expansion (see the sweep): highest order, fewest maskers worth it, and for each supported order J the
+// largest |x| with |x|^(J+1)/(J+1)! e^|x| below 1e-17 (x = slope spread * half the Bark span of a group of lines)
+constexpr int kFarMaxOrder = 20;
+constexpr int kFarMinMaskers = 24;
+constexpr double kFarLimit8 = 0.052, kFarLimit12 = 0.27, kFarLimit16 = 0.68, kFarLimit20 = 1.0;
+#ifndef MRC_FAR_MAX_ORDER                        // 20 costs 48 accumulator registers: spills around every chunk
+#define MRC_FAR_MAX_ORDER 16
+#endif
+constexpr double kFarLimitMax = MRC_FAR_MAX_ORDER >= 20 ? kFarLimit20 : MRC_FAR_MAX_ORDER >= 16 ? kFarLimit16 : kFarLimit12;
+constexpr double kInvFactorial[kFarMaxOrder + 1] = {
     1.0, 1.0, 1.0 / 2, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880,
     1.0 / 3628800, 1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0, 1.0 / 87178291200.0,
-    1.0 / 1307674368000.0, 1.0 / 20922789888000.0};
+    1.0 / 1307674368000.0, 1.0 / 20922789888000.0, 1.0 / 355687428096000.0, 1.0 / 6402373705728000.0,
+    1.0 / 121645100408832000.0, 1.0 / 2432902008176640000.0};
 constexpr double kLog2Of10 = 0x1.a934f0979a371p+1;     // log2(10) = hi + lo
 constexpr double kLog2Of10Lo = 0x1.7f2495fb7fa6dp-53;
 // b = -2.7*log2(10) bits per Bark below the masker (psychoac.py:74), split hi + lo
@@ -124,41 +130,87 @@ __device__ __forceinline__ void dd_add(double* hi, double* lo, double xh, double
     *hi = h;
 }
 
-// Sum each of 16 per-lane values over the 64 lanes of the wave and leave all 16 totals in every lane.
-// A "transposing" butterfly: at distance 32, 16, 8, 4 every lane hands HALF of its remaining values to its
-// partner and adds the partner's half of the others (8 + 4 + 2 + 1 exchanges instead of 16 x 6), which
-// leaves lane l with the partial sum of value number (l >> 2) & 15; two plain butterfly steps finish it and
-// 16 broadcasts distribute the totals.
-__device__ __forceinline__ void wave_sum_16(double* v, int lane) {
-    double w[8];
-    const bool h5 = lane & 32;
+// Sum each of N per-lane values over the 64 lanes of the wave and leave all N totals in every lane.
+// Blocks of W = 16 or 8 values go through a "transposing" butterfly: at every halving step a lane hands HALF of its
+// remaining values to its partner and adds the partner's half of the others (W/2 + W/4 + ... + 1 exchanges instead
+// of W x 6); plain butterfly steps finish the one value left per lane and W broadcasts distribute the totals.
+// Values beyond the last full block are reduced one by one.
+template <int W>
+__device__ __forceinline__ void wave_sum_block(double* v, int lane) {
+    static_assert(W == 16 || W == 8, "block of 16 or 8 values");
+    double w[W / 2];
+    int dist = 32;
+    {
+        const bool hi = lane & dist;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const double send = h5 ? v[i] : v[i + 8];
-        const double keep = h5 ? v[i + 8] : v[i];
-        w[i] = keep + __shfl_xor(send, 32);
+        for (int i = 0; i < W / 2; ++i) {
+            const double send = hi ? v[i] : v[i + W / 2];
+            const double keep = hi ? v[i + W / 2] : v[i];
+            w[i] = keep + __shfl_xor(send, dist);
+        }
     }
-    const bool h4 = lane & 16;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const double send = h4 ? w[i] : w[i + 4];
-        const double keep = h4 ? w[i + 4] : w[i];
-        w[i] = keep + __shfl_xor(send, 16);
+    for (int n = W / 4; n >= 1; n >>= 1) {
+        dist >>= 1;
+        const bool hi = lane & dist;
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+            const double send = hi ? w[i] : w[i + n];
+            const double keep = hi ? w[i + n] : w[i];
+            w[i] = keep + __shfl_xor(send, dist);
+        }
     }
-    const bool h3 = lane & 8;
+    double s = w[0];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const double send = h3 ? w[i] : w[i + 2];
-        const double keep = h3 ? w[i + 2] : w[i];
-        w[i] = keep + __shfl_xor(send, 8);
+    for (int d = dist >> 1; d >= 1; d >>= 1) s += __shfl_xor(s, d);
+    // the lane whose top log2(W) bits spell j (most significant first) holds the total of value j
+#pragma unroll
+    for (int j = 0; j < W; ++j) v[j] = __shfl(s, j * (kWave / W));
+}
+
+// blocks of 8 only: a block of 16 would save three exchanges per 16 values but keeps 24 doubles live at once
+template <int N>
+__device__ __forceinline__ void wave_sum_all(double* v, int lane) {
+    constexpr int n8 = N / 8;
+#pragma unroll
+    for (int i = 0; i < n8; ++i) wave_sum_block<8>(v + 8 * i, lane);
+#pragma unroll
+    for (int j = 8 * n8; j < N; ++j) {
+        double t = v[j];
+#pragma unroll
+        for (int offl = 32; offl > 0; offl >>= 1) t += __shfl_xor(t, offl);
+        v[j] = t;
     }
-    const bool h2 = lane & 4;
-    double s = (h2 ? w[1] : w[0]) + __shfl_xor(h2 ? w[0] : w[1], 4);
-    s += __shfl_xor(s, 2);
-    s += __shfl_xor(s, 1);
-    // lane l now holds the total of value number 8*b5 + 4*b4 + 2*b3 + b2 of its own lane bits
+}
+
+// Far field of one group of lines (see the sweep): maskers [0, nFar) lie more than 1/2 Bark below every line of
+// the group.  With c the group's centre, d = z - c, a_m = s_m ln2 the masker's slope and A any reference slope,
+//   sum_m I_m 2^(s_m (z - z_m - 1/2)) = exp(A d) sum_m e_m exp((a_m - A) d) = exp(A d) sum_j d^j/j! B_j,
+//   e_m = I_m 2^(s_m (c - z_m - 1/2)),  B_j = sum_m e_m (a_m - A)^j.
+// Lanes take maskers (ONE 2^x per masker and group instead of one per masker and line), the J+1 coefficients are
+// wave-reduced, every line evaluates the polynomial and one 2^x.  The caller picks J from |a_m - A| |d|.
+// NB = J + 1 padded to what wave_sum_all reduces cheapest.
+template <int J, int NB>
+__device__ __forceinline__ double far_group(const double* __restrict__ mt, int nFar, double cq, double slMid,
+                                            double d, int lane, const double* __restrict__ e2tab) {
+    double B[NB];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = __shfl(s, j << 2);
+    for (int j = 0; j < NB; ++j) B[j] = 0.0;
+    for (int m = lane; m < nFar; m += kWave) {
+        const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
+        double term = I * exp2_tab64(sl, cq - zm, e2tab);                   // cq - zm > 0 for m < nFar
+        const double da = (sl - slMid) * (0.6931471805599453094 / 64.0);   // slope offset in nats per Bark
+#pragma unroll
+        for (int j = 0; j <= J; ++j) {
+            B[j] += term;
+            term *= da;
+        }
+    }
+    wave_sum_all<NB>(B, lane);
+    double p = B[J] * kInvFactorial[J];
+#pragma unroll
+    for (int j = J - 1; j >= 0; --j) p = fma(p, d, B[j] * kInvFactorial[j]);
+    return p * exp2_tab64(slMid, d, e2tab);
 }
 
 // kLog10Tab as [j][4] for the LDS copy
@@ -212,6 +264,13 @@ __device__ unsigned long long gPhaseCycles[16];
 #define MRC_SMR_OCC
 #endif
 
+#ifndef MRC_DIRECT_UNROLL                        // pairs in flight per lane in the direct loops
+#define MRC_DIRECT_UNROLL 4
+#endif
+#ifndef MRC_PROFILE_SKIP                         // profiling aid (wrong results): bit mask of sweep parts to leave out,
+#define MRC_PROFILE_SKIP 0                       // 1 far field, 2 direct pairs, 4 partial pairs, 8 chunk tail
+#endif
+
 template <bool EXACT>
 __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, int nsig, const double* __restrict__ chL,
                                                        const double* __restrict__ chR, int64_t stride,
@@ -222,6 +281,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     extern __shared__ double smem[];
     __shared__ int waveCnt[kThreads / kWave];
     __shared__ unsigned long long bandKey[kMaxBands];   // per-band running max of the excess (order-preserving key)
+    __shared__ unsigned long long slopeKey[2];          // min / max upper slope over the frame's maskers (keys)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6;
     const int H = S.H, M = S.halfN;
@@ -242,6 +302,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     long long tPhase_ = clock64();
 #endif
     if (tid < kMaxBands) bandKey[tid] = 0ull;           // below every key; visible after the first barrier
+    if (tid < 2) slopeKey[tid] = tid ? 0ull : ~0ull;
     const double* zbS = smem + lay.zbOff;               // staged after the FFT (the area is FFT scratch / dead)
     const double* e2tab = smem + 2 * H - kExpTab;       // 2^(j/64): the tail of region A, behind the masker table
     const double* logTab = smem + lay.logOff;
@@ -335,6 +396,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
         for (int k = tid; k <= M; k += kThreads) { cntArr[k] = 0; nUpArr[k] = 0; }
     __syncthreads();
     MRC_PHASE(3);
+    double slLo = 1e300, slHi = -1e300;                 // this thread's maskers: range of the upper slope
     for (int mi = tid; mi < nPeaks; mi += kThreads) {
         const int p = pkBin[mi];
         const int before = mi;
@@ -361,6 +423,8 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                 const double pl = fma(kLowHi, zm, -ph) + kLowLo * zm;
                 e[0] = I;
                 e[2] = (((-27 + boost) / 10) * kLog2Of10) * 64.0;          // upper slope, 1/64 bit per Bark
+                slLo = fmin(slLo, e[2]);
+                slHi = fmax(slHi, e[2]);
                 e[3] = I * exp2_dd(ph, pl);
                 // first line that sees this masker at all (fl(z_k - z_m) >= -1/2) and first line more than
                 // 1/2 Bark above it (fl(z_k - z_m) > 1/2): both predicates are monotone in k
@@ -377,6 +441,14 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                 }
                 atomicAdd(reinterpret_cast<unsigned int*>(nUpArr) + (lo >> 1), 1u << (16 * (lo & 1)));
             }
+        }
+    }
+    if (!EXACT) {
+        slLo = -wave_max(-slLo);
+        slHi = wave_max(slHi);
+        if (lane == 0) {
+            atomicMin(&slopeKey[0], order_key(slLo));
+            atomicMax(&slopeKey[1], order_key(slHi));
         }
     }
     __syncthreads();
@@ -515,8 +587,68 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
             const int kc = min(chunk_of(i) * kWave + lane, M - 1);
             return LineConst{S.zb[kc], S.quiet[kc], S.lowE[kc], X[kc], S.bandOfLine[kc]};
         };
-        LineConst nxt = load_consts(0);
-        for (int i = 0;; ++i) {
+        const double slMid = 0.5 * (order_value(slopeKey[0]) + order_value(slopeKey[1]));
+        const double spreadHalf = 0.5 * (order_value(slopeKey[1]) - order_value(slopeKey[0])) * (0.6931471805599453094 / 64.0);
+        // Rounds of up to four chunks per wave.  Pass 1 evaluates the FAR FIELD of the round's chunks -- the only part
+        // that needs a large register tile (the expansion coefficients) -- and keeps one value per line; pass 2 does
+        // the near maskers, the in-band and lower-side sums and the SPL conversions with that value added in.
+        for (int i0 = 0; chunk_of(i0) < nChunks; i0 += 4) {
+        // ---- pass 1: far field.  Maskers [0, nFar) lie more than 1/2 Bark below EVERY line of the chunk; their sum is
+        // evaluated by far_group() for the whole chunk (one group) or its two halves.  The expansion is in
+        // (slope - middle slope of the frame) x (distance from the group's centre): the order follows from
+        // half the slope range times half the Bark span, so a frame of similar maskers (noise) gets by with a low
+        // order even where 64 lines span more than a Bark, and a frame with a loud and a quiet region still
+        // qualifies at the top of the spectrum.  The truncated tail is < 1e-17 of each term.
+        double far0 = 0.0, far1 = 0.0, far2 = 0.0, far3 = 0.0;
+        unsigned farMask = 0;                            // bit u: chunk u of the round took the far field
+        for (int u = 0; u < 4; ++u) {
+            const int c = chunk_of(i0 + u);
+            if (c >= nChunks) break;
+            const int kc = min(c * kWave + lane, M - 1);
+            const int nFar = __builtin_amdgcn_readfirstlane((int)nUpArr[kc]);      // nUp of the chunk's first line
+            if (nFar < kFarMinMaskers || (MRC_PROFILE_SKIP & 1)) continue;
+            const double z = S.zb[kc];
+            const double zFirst = __shfl(z, 0), zLast = __shfl(z, kWave - 1);
+            const double zHalfEnd = __shfl(z, kWave / 2 - 1), zHalfBeg = __shfl(z, kWave / 2);
+            const double need1 = spreadHalf * (0.5 * (zLast - zFirst));
+            const double need2 = spreadHalf * (0.5 * fmax(zHalfEnd - zFirst, zLast - zHalfBeg));
+            double need = need1;
+            int nGroups = 1;
+            if (need1 > kFarLimitMax) { need = need2; nGroups = 2; }
+            const int order = need <= kFarLimit8 ? 8 : need <= kFarLimit12 ? 12 :
+                              (MRC_FAR_MAX_ORDER >= 16 && need <= kFarLimit16) ? 16 :
+                              (MRC_FAR_MAX_ORDER >= 20 && need <= kFarLimit20) ? 20 : 0;
+            if (!order) continue;
+            const int myGroup = (nGroups == 2) ? (lane >> 5) : 0;
+            double acc = 0.0;
+            for (int g = 0; g < nGroups; ++g) {
+                const double cg = (nGroups == 1) ? 0.5 * (zFirst + zLast)
+                                                 : (g == 0 ? 0.5 * (zFirst + zHalfEnd) : 0.5 * (zHalfBeg + zLast));
+                const double cq = cg - 0.5, d = z - cg;
+                double p;
+                if (order == 8) p = far_group<8, 9>(mt, nFar, cq, slMid, d, lane, e2tab);
+                else if (order == 12) p = far_group<12, 16>(mt, nFar, cq, slMid, d, lane, e2tab);
+#if MRC_FAR_MAX_ORDER >= 20
+                else if (order == 20) p = far_group<20, 24>(mt, nFar, cq, slMid, d, lane, e2tab);
+#endif
+#if MRC_FAR_MAX_ORDER >= 16
+                else if (order == 16) p = far_group<16, 17>(mt, nFar, cq, slMid, d, lane, e2tab);
+#endif
+                else p = 0.0;
+                if (g == myGroup) acc = p;
+            }
+            farMask |= 1u << u;
+            far0 = u == 0 ? acc : far0;
+            far1 = u == 1 ? acc : far1;
+            far2 = u == 2 ? acc : far2;
+            far3 = u == 3 ? acc : far3;
+        }
+        MRC_PHASE(7);
+        // ---- pass 2.  The per-line constants of the NEXT chunk are loaded while this one is computed (loop-carried,
+        // so the global-load latency is never exposed between the loops of a chunk)
+        LineConst nxt = load_consts(i0);
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u;
             const int c = chunk_of(i);
             if (c >= nChunks) break;
             const int k = c * kWave + lane;
@@ -524,7 +656,8 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
             const LineConst cur = nxt;
             nxt = load_consts(i + 1);
             const double z = cur.z;
-            double tot = cur.quiet;
+            // quiet threshold + far field (psychoac.py:155,166-168; the order of the additions is free, see above)
+            double tot = cur.quiet + (u == 0 ? far0 : u == 1 ? far1 : u == 2 ? far2 : far3);
             const int cnt = cntArr[kc], nUp = nUpArr[kc];      // maskers that reach the line / lie > 1/2 Bark below it
             int mLow = cnt, mEnd = cnt, mExp = nUp;
 #pragma unroll
@@ -536,73 +669,21 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
             mLow = __builtin_amdgcn_readfirstlane(mLow);
             mEnd = __builtin_amdgcn_readfirstlane(mEnd);
             mExp = __builtin_amdgcn_readfirstlane(mExp);
-#ifndef MRC_PROFILE_SKIP                         // profiling aid (wrong results): bit mask of sweep parts to leave out,
-#define MRC_PROFILE_SKIP 0                       // 1 far field, 2 direct pairs, 4 partial pairs, 8 chunk tail
-#endif
             const int mPlain = min(mExp, mLow);
             const double zq = z - 0.5;                 // u = max(z - z_m - 1/2, 0), one subtraction per pair
+            const int mFirst = ((farMask >> u) & 1u) ? __builtin_amdgcn_readfirstlane(nUp) : 0;
             MRC_PHASE(6);
-
-            // ---- far field by local expansion.  Maskers [0, nFar) lie more than 1/2 Bark below EVERY line
-            // of the chunk, so their sum  sum_m I_m 2^(s_m (z - z_m - 1/2))  is smooth in z over the chunk:
-            // with a = s_m ln2 and d = z - c (c = centre of a group of lines),
-            //   sum_m e_m exp(a_m d) = sum_j d^j/j! * B_j,   B_j = sum_m e_m a_m^j,   e_m = I_m 2^(s_m (c - z_m - 1/2)).
-            // Lanes take maskers (one 2^x per masker and group instead of one per masker and LINE), B_j is
-            // wave-reduced, every line evaluates the degree-J polynomial.  |a| <= 8.97 ln2 and |d| <= kFarSpan/2
-            // give |a d| <= 0.7: the truncated tail is < 1.3e-17 of each term (relative, term by term).
-            int mFirst = 0;
-            {
-                const double zFirst = __shfl(z, 0), zLast = __shfl(z, kWave - 1);
-                const double zHalfEnd = __shfl(z, kWave / 2 - 1), zHalfBeg = __shfl(z, kWave / 2);
-                const int nFar = __builtin_amdgcn_readfirstlane(nUp);          // nUp of the chunk's first line
-                int nGroups = 0;
-                if (zLast - zFirst <= kFarSpan) nGroups = 1;
-                else if (zHalfEnd - zFirst <= kFarSpan && zLast - zHalfBeg <= kFarSpan) nGroups = 2;
-                if (nGroups && nFar >= kFarMinMaskers) {
-                    const int myGroup = (nGroups == 2) ? (lane >> 5) : 0;
-                    for (int g = 0; g < nGroups; ++g) {
-                        const double c = (nGroups == 1) ? 0.5 * (zFirst + zLast)
-                                                        : (g == 0 ? 0.5 * (zFirst + zHalfEnd) : 0.5 * (zHalfBeg + zLast));
-                        const double cq = c - 0.5;
-                        if (MRC_PROFILE_SKIP & 1) continue;
-                        double B[kFarOrder + 1];
-#pragma unroll
-                        for (int j = 0; j <= kFarOrder; ++j) B[j] = 0.0;
-                        for (int m = lane; m < nFar; m += kWave) {
-                            const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
-                            double term = I * exp2_tab64(sl, cq - zm, e2tab);          // cq - zm > 0 for m < nFar
-                            const double a = sl * (0.6931471805599453094 / 64.0);     // slope in nats per Bark
-#pragma unroll
-                            for (int j = 0; j <= kFarOrder; ++j) {
-                                B[j] += term;
-                                term *= a;
-                            }
-                        }
-                        const double d = z - c;
-                        wave_sum_16(B, lane);                          // B[0..15]: totals over the wave, in every lane
-                        double top = B[kFarOrder];
-#pragma unroll
-                        for (int offl = 32; offl > 0; offl >>= 1) top += __shfl_xor(top, offl);
-                        double p = top * kInvFactorial[kFarOrder];
-#pragma unroll
-                        for (int j = kFarOrder - 1; j >= 0; --j) p = fma(p, d, B[j] * kInvFactorial[j]);
-                        if (g == myGroup) tot += p;
-                    }
-                    mFirst = nFar;
-                }
-            }
-            MRC_PHASE(7);
             // some line of the chunk is above the masker's band, every line sees the masker.  Maskers below
             // nUp of the chunk's FIRST line are more than 1/2 Bark below every line: u > 0 without the clamp.
             {
                 const int mPos = min(max(__builtin_amdgcn_readfirstlane(nUp), mFirst), mPlain);
                 const int mStop = (MRC_PROFILE_SKIP & 2) ? 0 : mPlain;
-#pragma unroll 4
+#pragma unroll MRC_DIRECT_UNROLL
                 for (int m = mFirst; m < min(mPos, mStop); ++m) {
                     const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
                     tot = fma(I, exp2_tab64(sl, zq - zm, e2tab), tot);
                 }
-#pragma unroll 4
+#pragma unroll MRC_DIRECT_UNROLL
                 for (int m = mPos; m < mStop; ++m) {
                     const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
                     const double u = fmax(zq - zm, 0.0);
@@ -645,6 +726,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                 atomicMax(&bandKey[bnd], order_key(ex));
             }
             MRC_PHASE(10);
+        }
         }
     }
     __syncthreads();

@@ -86,3 +86,42 @@ for huff in (False, True):
     print(json.dumps({"workload": "host pack_joint_blocks (C++, 1 thread), huffman=%s" % huff, "frames": n,
                       "Msamples_per_s": round(2 * n * 1024 / dt / 1e6, 1), "bytes_per_frame": round(len(data) / n, 1),
                       "kbit_per_s_at_48k": round(len(data) * 8 / (n * 1024 / 48000) / 1e3, 1)}), flush=True)
+
+# ---- decode side: fused dequantise / M-S / IMDCT / window / overlap-add of the joint output above, device resident
+Fd = F
+o_dev = enc.encode_long(L, R, Fd)
+offs_d = (torch.arange(Fd, device=dev, dtype=torch.int64) * 1024).contiguous()
+pcm_f = torch.zeros((2, (Fd + 1) * 1024), dtype=torch.float64, device=dev)
+pcm_i = torch.empty((2, (Fd + 1) * 1024), dtype=torch.int16, device=dev)
+st = torch.cuda.current_stream(dev).cuda_stream
+
+
+def run_decode():
+    pcm_f.zero_()
+    enc.h.dev_decode(1024, 1024, Fd, 2, o_dev["overall_scale"].data_ptr(), o_dev["ms_switch"].data_ptr(),
+                     o_dev["scale_factor"].data_ptr(), o_dev["bit_alloc"].data_ptr(), o_dev["mantissa"].data_ptr(),
+                     offs_d.data_ptr(), pcm_f[0].data_ptr(), pcm_f[1].data_ptr(), st)
+    enc.h.dev_pcm16(pcm_f.numel(), pcm_f.data_ptr(), pcm_i.data_ptr(), st)
+
+
+dt = timed(run_decode)
+err = (pcm_f[0, 2048:Fd * 1024] - L[2048:Fd * 1024])
+snr = 10 * torch.log10((L[2048:Fd * 1024] ** 2).sum() / (err ** 2).sum()).item()
+print(json.dumps({"workload": "decode: joint stereo long blocks, dequantise..overlap-add + pcm16, device resident",
+                  "frames": Fd, "ms_per_step": round(dt * 1e3, 3), "Msamples_per_s": round(2 * Fd * 1024 / dt / 1e6, 1),
+                  "algorithmic_GBs": round(Fd * 2 * (4096 + 200 + 8192 * 2 + 2048) / dt / 1e9, 1),
+                  "left_channel_snr_db_white_noise": round(snr, 2)}), flush=True)
+
+# ---- host parser: C++ header / chunk parser of a packed stream (single thread)
+data, offs_b, _, _ = pacfile.pack_joint_blocks(cfg, 1024, 1024, o["overall_scale"], o["ms_switch"], o["scale_factor"],
+                                               o["bit_alloc"], o["mantissa"], True)
+blob = pacfile.header(cfg, 2, n * 1024) + data.tobytes()
+cfg2, nch, _, off0 = pacfile.read_header(blob)
+cfg2.n_short, cfg2.blksw_bits_a, cfg2.blksw_bits_b = 128, 1, 1
+t0 = time.perf_counter()
+chunks = pacfile.scan_chunks(blob, off0)
+parsed = pacfile.unpack_blocks(cfg2, blob, chunks, 2, True)
+dt = time.perf_counter() - t0
+assert (parsed["mantissa"] == o["mantissa"]).all()
+print(json.dumps({"workload": "host unpack_blocks (C++, 1 thread), huffman=True", "frames": n,
+                  "Msamples_per_s": round(2 * n * 1024 / dt / 1e6, 1)}), flush=True)
