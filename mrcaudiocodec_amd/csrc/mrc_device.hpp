@@ -99,17 +99,20 @@ template <> __device__ __forceinline__ void butterfly<4>(double2* u) {
 // global-load latency inside the passes (the FFT of a block is a chain of dependent, barrier-separated passes).
 struct TwGlobal {
     const double2* __restrict__ w;
-    __device__ __forceinline__ double2 operator()(int t) const { return w[t]; }
+    __device__ __forceinline__ double2 operator()(int t, int /*nq*/) const { return w[t]; }
 };
 struct TwQuarter {
     const double2* w;                                   // LDS, [n/4]
     int mask, shift;                                    // n/4 - 1, log2(n/4)
-    __device__ __forceinline__ double2 operator()(int t) const {
+    // nq: t is known to lie in quadrants 0 .. nq-1 (a compile-time constant after unrolling, so the unused fix-ups
+    // fold away): input r of a radix-R butterfly has t = k r tws < r n/R
+    __device__ __forceinline__ double2 operator()(int t, int nq) const {
         const double2 v = w[t & mask];
-        const int q = t >> shift;                       // 0..2 (t < 3n/4)
-        double2 r = (q & 1) ? make_double2(v.y, -v.x) : v;
-        if (q & 2) r = make_double2(-r.x, -r.y);
-        return r;
+        if (nq <= 1) return v;
+        const int q = t >> shift;
+        double2 o = (q & 1) ? make_double2(v.y, -v.x) : v;
+        if (nq >= 3 && (q & 2)) o = make_double2(-o.x, -o.y);
+        return o;
     }
 };
 
@@ -131,7 +134,7 @@ __device__ __forceinline__ void fft_pass(const double2* __restrict__ in, double2
         for (int r = 0; r < R; ++r) u[r] = in[i + r * T];
         if (!first) {
 #pragma unroll
-            for (int r = 1; r < R; ++r) u[r] = cmul(u[r], W(k * r * tws));
+            for (int r = 1; r < R; ++r) u[r] = cmul(u[r], W(k * r * tws, (4 * r + R - 1) / R));
         }
         butterfly<R>(u);
 #pragma unroll

@@ -326,6 +326,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
         }
     }
     const int last = S.peakLast;                        // bins 0 .. last-1 are inspected (psychoac.py:160)
+    const double xiInv = 1.0 / S.xiDen;
     double2* T;
     if (lay.twOff >= 0) {
         double2* Wq = reinterpret_cast<double2*>(smem + lay.twOff);
@@ -355,7 +356,8 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                 double2 od = make_double2(0.5 * d.y, -0.5 * d.x);
                 double2 X = cmul(wn[u], od);
                 X.x += ev.x; X.y += ev.y;
-                xi[k] = 4. * (X.x * X.x + X.y * X.y) / S.xiDen;  // psychoac.py:151
+                xi[k] = EXACT ? 4. * (X.x * X.x + X.y * X.y) / S.xiDen      // psychoac.py:151
+                              : (4. * (X.x * X.x + X.y * X.y)) * xiInv;     // (one rounding more)
             }
         }
     }
@@ -659,16 +661,9 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
             // quiet threshold + far field (psychoac.py:155,166-168; the order of the additions is free, see above)
             double tot = cur.quiet + (u == 0 ? far0 : u == 1 ? far1 : u == 2 ? far2 : far3);
             const int cnt = cntArr[kc], nUp = nUpArr[kc];      // maskers that reach the line / lie > 1/2 Bark below it
-            int mLow = cnt, mEnd = cnt, mExp = nUp;
-#pragma unroll
-            for (int offl = 32; offl > 0; offl >>= 1) {
-                mLow = min(mLow, __shfl_xor(mLow, offl));
-                mEnd = max(mEnd, __shfl_xor(mEnd, offl));
-                mExp = max(mExp, __shfl_xor(mExp, offl));
-            }
-            mLow = __builtin_amdgcn_readfirstlane(mLow);
-            mEnd = __builtin_amdgcn_readfirstlane(mEnd);
-            mExp = __builtin_amdgcn_readfirstlane(mExp);
+            // both counts are non-decreasing in the line index: the chunk's bounds sit in its first and last lane
+            const int mLow = __builtin_amdgcn_readfirstlane(cnt);                      // min cnt
+            const int mExp = __builtin_amdgcn_readlane(nUp, kWave - 1);                // max nUp
             const int mPlain = min(mExp, mLow);
             const double zq = z - 0.5;                 // u = max(z - z_m - 1/2, 0), one subtraction per pair
             const int mFirst = ((farMask >> u) & 1u) ? __builtin_amdgcn_readfirstlane(nUp) : 0;
