@@ -224,7 +224,7 @@ int mrc_dev_smr(mrc_handle* h, int a, int b, int64_t n_frames, const double* ch_
     int rc = get_shape(h, a, b, &hs);
     if (rc) return rc;
     MRC_HIP(h, launch_smr(hs->dev, n_frames, ch_left, ch_right, frame_stride, offsets, lines, overall_scale, smr,
-                          thresh, h->exactSpread, pick_stream(h, stream)));
+                          thresh, nullptr, h->exactSpread, pick_stream(h, stream)));
     return MRC_OK;
 }
 
@@ -241,7 +241,7 @@ int mrc_dev_alloc_quant(mrc_handle* h, int a, int b, int64_t n_frames, int joint
     MRC_HIP(h, hipSetDevice(h->device));
     MRC_HIP(h, h->wsPeak.reserve(alloc_workspace_bytes(hs->dev, n_frames, joint)));
     MRC_HIP(h, launch_alloc_quant(hs->dev, n_frames, joint, lines, overall_scale, smr, reservoir_in, ms_switch,
-                                  bit_alloc, scale_factor, mantissa, reservoir_out, h->wsPeak.as<double>(),
+                                  bit_alloc, scale_factor, mantissa, reservoir_out, h->wsPeak.as<double>(), false,
                                   pick_stream(h, stream)));
     return MRC_OK;
 }
@@ -306,10 +306,11 @@ int mrc_dev_encode(mrc_handle* h, int a, int b, int64_t n_frames, const double* 
     if (h->timing) MRC_HIP(h, hipEventRecord(h->ev[0], st));
     MRC_HIP(h, launch_mdct(S, n_frames, ch_left, ch_right, frame_stride, offsets, true, lines, overall_scale, st));
     if (h->timing) MRC_HIP(h, hipEventRecord(h->ev[1], st));
-    MRC_HIP(h, launch_smr(S, n_frames, ch_left, ch_right, frame_stride, offsets, lines, overall_scale, smr, nullptr, h->exactSpread, st));
+    MRC_HIP(h, launch_smr(S, n_frames, ch_left, ch_right, frame_stride, offsets, lines, overall_scale, smr, nullptr,
+                          h->wsPeak.as<double>(), h->exactSpread, st));
     if (h->timing) MRC_HIP(h, hipEventRecord(h->ev[2], st));
     MRC_HIP(h, launch_alloc_quant(S, n_frames, joint, lines, overall_scale, smr, reservoir_in, ms_switch, bit_alloc,
-                                  scale_factor, mantissa, reservoir_out, h->wsPeak.as<double>(), st));
+                                  scale_factor, mantissa, reservoir_out, h->wsPeak.as<double>(), true, st));
     if (h->timing) {
         MRC_HIP(h, hipEventRecord(h->ev[3], st));
         MRC_HIP(h, hipEventSynchronize(h->ev[3]));
@@ -462,7 +463,8 @@ int mrc_smr(mrc_handle* h, int64_t n, int a, int b, const double* blocks, const 
                                h->outA.as<int>(), h->stream));
     }
     MRC_HIP(h, launch_smr(S, n, h->inL.as<double>(), nullptr, S.N, nullptr, h->outG.as<double>(), h->outA.as<int>(),
-                          h->outC.as<double>(), thresh ? h->outE.as<double>() : nullptr, h->exactSpread, h->stream));
+                          h->outC.as<double>(), thresh ? h->outE.as<double>() : nullptr, nullptr, h->exactSpread,
+                          h->stream));
     MRC_TRY(s.down(smr, h->outC, szSmr));
     if (thresh) MRC_TRY(s.down(thresh, h->outE, szLines));
     MRC_HIP(h, hipStreamSynchronize(h->stream));

@@ -69,11 +69,12 @@ hipError_t launch_unscale(int64_t nBlocks, int halfN, const double* scaled, cons
                           hipStream_t st);
 hipError_t launch_smr(const DevShape& S, int64_t nFrames, const double* chL, const double* chR,
                       int64_t stride, const int64_t* offsets, const double* lines, const int* oscale,
-                      double* smr, double* thresh, bool exactSpread, hipStream_t st);
+                      double* smr, double* thresh, double* bandPeak /* [frames*signals][nBands] or null */,
+                      bool exactSpread, hipStream_t st);
 hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, const double* lines,
                               const int* oscale, const double* smr, const int* resIn, int* msSwitch,
                               int* bitAlloc, int* scaleFactor, int* mantissa, int* resOut, double* bandPeakWs,
-                              hipStream_t st);
+                              bool peaksReady /* bandPeakWs already filled by launch_smr */, hipStream_t st);
 size_t alloc_workspace_bytes(const DevShape& S, int64_t nFrames, int joint);   // bandPeakWs size
 // mrc_kernels_decode.hip
 hipError_t launch_decode(const DevShape& S, int64_t nBlocks, int nStreams, const int* oscale, const int* msSwitch,

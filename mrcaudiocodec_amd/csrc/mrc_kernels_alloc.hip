@@ -18,7 +18,8 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // band statistics: one wavefront per frame
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kWave) void band_stats_kernel(DevShape S, int joint, const double* __restrict__ lines,
+__global__ __launch_bounds__(kWave) void band_stats_kernel(DevShape S, int joint, int wantPeaks,
+                                                           const double* __restrict__ lines,
                                                            int* __restrict__ msSwitch, double* __restrict__ bandPeak) {
     __shared__ unsigned long long peakBits[4 * kMaxBands];
     const int lane = threadIdx.x;
@@ -29,14 +30,14 @@ __global__ __launch_bounds__(kWave) void band_stats_kernel(DevShape S, int joint
     for (int i = lane; i < nsig * nb; i += kWave) peakBits[i] = 0ull;
     __syncthreads();
     // max |X| per band: |x| >= 0, so the raw bit pattern orders like the value
-    for (int s = 0; s < nsig; ++s)
+    for (int s = 0; s < (wantPeaks ? nsig : 0); ++s)
         for (int k = lane; k < M; k += kWave)
             atomicMax(&peakBits[s * nb + S.bandOfLine[k]],
                       (unsigned long long)__double_as_longlong(fabs(X[s * M + k])));
     if (joint && lane < nb)                              // on the UNSCALED L/R lines (codecThem.py:436)
         msSwitch[f * nb + lane] = ms_switch_band(X, X + M, S.bandLo[lane], S.bandN[lane]);
     __syncthreads();
-    for (int i = lane; i < nsig * nb; i += kWave)
+    for (int i = lane; i < (wantPeaks ? nsig * nb : 0); i += kWave)
         bandPeak[f * nsig * nb + i] = __longlong_as_double((long long)peakBits[i]);
 }
 
@@ -199,11 +200,13 @@ size_t alloc_workspace_bytes(const DevShape& S, int64_t nFrames, int joint) {
 
 hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, const double* lines, const int* oscale,
                               const double* smr, const int* resIn, int* msSwitch, int* bitAlloc, int* scaleFactor,
-                              int* mantissa, int* resOut, double* bandPeakWs, hipStream_t st) {
+                              int* mantissa, int* resOut, double* bandPeakWs, bool peaksReady, hipStream_t st) {
     if (nFrames <= 0) return hipSuccess;
     const int nTot = (joint ? 2 : 1) * S.nBands;
-    hipLaunchKernelGGL(band_stats_kernel, dim3((unsigned)nFrames), dim3(kWave), 0, st, S, joint, lines, msSwitch,
-                       bandPeakWs);
+    // the per-band peaks come from smr_kernel on the full path; this kernel is then only the M/S decision (joint)
+    if (joint || !peaksReady)
+        hipLaunchKernelGGL(band_stats_kernel, dim3((unsigned)nFrames), dim3(kWave), 0, st, S, joint, peaksReady ? 0 : 1,
+                           lines, msSwitch, bandPeakWs);
     const size_t lds = (size_t)nTot * kWave * (sizeof(double) + 1) + (size_t)nTot * sizeof(int);
     hipLaunchKernelGGL(bitalloc_kernel, dim3((unsigned)((nFrames + kWave - 1) / kWave)), dim3(kWave), lds, st, S, joint,
                        nFrames, smr, msSwitch, resIn, bitAlloc, resOut);

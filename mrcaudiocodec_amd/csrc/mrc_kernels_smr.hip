@@ -277,11 +277,13 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                                                        const int64_t* __restrict__ offsets,
                                                        const double* __restrict__ lines,
                                                        const int* __restrict__ oscale, double* __restrict__ smr,
-                                                       double* __restrict__ thresh, SmrLds lay) {
+                                                       double* __restrict__ thresh, double* __restrict__ bandPeak,
+                                                       SmrLds lay) {
     extern __shared__ double smem[];
     __shared__ int waveCnt[kThreads / kWave];
     __shared__ unsigned long long bandKey[kMaxBands];   // per-band running max of the excess (order-preserving key)
     __shared__ unsigned long long slopeKey[2];          // min / max upper slope over the frame's maskers (keys)
+    __shared__ unsigned long long peakKey[kMaxBands];   // per-band max |X| (the bit pattern of |x| orders like |x|)
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6;
     const int H = S.H, M = S.halfN;
@@ -303,6 +305,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
 #endif
     if (tid < kMaxBands) bandKey[tid] = 0ull;           // below every key; visible after the first barrier
     if (tid < 2) slopeKey[tid] = tid ? 0ull : ~0ull;
+    if (tid < kMaxBands) peakKey[tid] = 0ull;
     const double* zbS = smem + lay.zbOff;               // staged after the FFT (the area is FFT scratch / dead)
     const double* e2tab = smem + 2 * H - kExpTab;       // 2^(j/64): the tail of region A, behind the masker table
     const double* logTab = smem + lay.logOff;
@@ -495,6 +498,8 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                     double xs = ldexp(X[k], scale);                              // codecThem.py:323 (exact)
                     double spl = spl_db(2. * (xs * xs) / (1. / 2.)) - 6. * scale;   // psychoac.py:212
                     atomicMax(&bandKey[S.bandOfLine[k]], order_key(spl - thr));
+                    if (bandPeak)
+                        atomicMax(&peakKey[S.bandOfLine[k]], (unsigned long long)__double_as_longlong(fabs(X[k])));
                 }
             }
         }
@@ -717,8 +722,13 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
             if (__all(bnd == __builtin_amdgcn_readfirstlane(bnd))) {
                 const double best = wave_max(ex);        // whole chunk inside one band (the wide top bands)
                 if (lane == 0) atomicMax(&bandKey[bnd], order_key(best));
+                if (bandPeak) {
+                    const double pk = wave_max(fabs(cur.x));
+                    if (lane == 0) atomicMax(&peakKey[bnd], (unsigned long long)__double_as_longlong(pk));
+                }
             } else {
                 atomicMax(&bandKey[bnd], order_key(ex));
+                if (bandPeak) atomicMax(&peakKey[bnd], (unsigned long long)__double_as_longlong(fabs(cur.x)));
             }
             MRC_PHASE(10);
         }
@@ -726,8 +736,12 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     }
     __syncthreads();
     MRC_PHASE(11);
-    for (int bnd = tid; bnd < S.nBands; bnd += kThreads)
+    for (int bnd = tid; bnd < S.nBands; bnd += kThreads) {
         smr[(int64_t)blockIdx.x * S.nBands + bnd] = order_value(bandKey[bnd]);
+        // max |X| per band of the UNSCALED lines: what the scale factors need (codecThem.py:346), so the back end
+        // does not have to read the lines once more for it
+        if (bandPeak) bandPeak[(int64_t)blockIdx.x * S.nBands + bnd] = __longlong_as_double((long long)peakKey[bnd]);
+    }
 }
 
 }  // namespace
@@ -746,7 +760,7 @@ extern "C" int mrc_debug_phase_cycles(unsigned long long* out16, int reset) {
 
 hipError_t launch_smr(const DevShape& S, int64_t nFrames, const double* chL, const double* chR, int64_t stride,
                       const int64_t* offsets, const double* lines, const int* oscale, double* smr, double* thresh,
-                      bool exactSpread, hipStream_t st) {
+                      double* bandPeak, bool exactSpread, hipStream_t st) {
     if (nFrames <= 0) return hipSuccess;
     const int nsig = chR ? 4 : 1;
     // dynamic LDS (doubles): FFT ping-pong [4H] + intensity spectrum [peakLast + 1].  The staged tables go into
@@ -776,10 +790,10 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const double* chL, con
     const size_t lds = (size_t)total * sizeof(double);
     if (exactSpread)
         hipLaunchKernelGGL(smr_kernel<true>, dim3((unsigned)(nFrames * nsig)), dim3(kThreads), lds, st, S, nsig, chL,
-                           chR, stride, offsets, lines, oscale, smr, thresh, lay);
+                           chR, stride, offsets, lines, oscale, smr, thresh, bandPeak, lay);
     else
         hipLaunchKernelGGL(smr_kernel<false>, dim3((unsigned)(nFrames * nsig)), dim3(kThreads), lds, st, S, nsig, chL,
-                           chR, stride, offsets, lines, oscale, smr, thresh, lay);
+                           chR, stride, offsets, lines, oscale, smr, thresh, bandPeak, lay);
     return hipGetLastError();
 }
 
