@@ -35,8 +35,10 @@ HOP = 1024
 HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8.0 TB/s spec
 # algorithmic bytes per long (frame, channel) -- DESIGN.md "Algorithmic bytes"
 BYTES_MDCT = 8192 + 8192                          # one new hop in (f64) + 1024 lines out (f64)
-BYTES_SMR = 8192 + 8192 + 4 + 25 * 8              # hop in + lines in + overall scale in + 25 SMRs out
-BYTES_ALLOC = 8192 + 4 + 25 * 8 + 4 + 4096 + 100 + 100 + 4   # lines, scale, SMRs, reservoir in; mantissas, sf, ba, reservoir out
+BYTES_SMR = 8192 + 8192 + 4 + 25 * 8 + 25 * 8     # hop in + lines in + overall scale in; 25 SMRs + 25 band peaks out
+# bitalloc: SMRs + reservoir in, allocation + reservoir out; quantize: lines, scale, band peaks, allocation in,
+# mantissas + scale factors out
+BYTES_ALLOC = (25 * 8 + 4 + 100 + 4) + (8192 + 4 + 25 * 8 + 100 + 4096 + 100)
 BYTES_PATH = 12496                                # hop in + all integer outputs
 
 
@@ -45,7 +47,9 @@ def measured_traffic():
     rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950 correction applied by
     tools/summarize_profiles.py).  bench.py cannot collect PMC counters itself; {} when no summary exists."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")),
+                   key=lambda f: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(f))])
     if not files:
         return {}, None
     with open(files[-1]) as f:
@@ -151,7 +155,7 @@ def main():
 
     if rank == 0:
         total_samples = float(F) * HOP * world * args.steps
-        names = ["mdct_long_kernel", "smr_kernel", "band_stats+bitalloc+quantize kernels"]
+        names = ["mdct_long_kernel", "smr_kernel", "bitalloc+quantize kernels"]
         per_unit = [BYTES_MDCT, BYTES_SMR, BYTES_ALLOC]
         kernels = []
         for nm, ms, bpu in zip(names, stage_ms, per_unit):
@@ -160,7 +164,7 @@ def main():
                             "achieved_GBs": round(gbs, 2), "frac_hbm": round(gbs / HBM_PEAK_GBS, 5)})
         dom = int(np.argmax(stage_ms))
         traffic, traffic_src = measured_traffic()
-        stage_kernels = [["mdct_long_kernel"], ["smr_kernel"], ["band_stats_kernel", "bitalloc_kernel", "quantize_kernel"]]
+        stage_kernels = [["mdct_long_kernel"], ["smr_kernel"], ["bitalloc_kernel", "quantize_kernel"]]
         for kinfo, parts in zip(kernels, stage_kernels):
             kinfo["traffic"] = round(sum(traffic[p] for p in parts) * F) if all(p in traffic for p in parts) else None
         line = {
@@ -178,7 +182,7 @@ def main():
             "roofline": {"kernel": names[dom], "bound": "hbm", "achieved": kernels[dom]["achieved_GBs"],
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[dom]["frac_hbm"],
                          "traffic": kernels[dom]["traffic"], "traffic_source": traffic_src,
-                         "limiter": "fp64 VALU issue (2^x polynomial per masker x line), not HBM -- DESIGN.md section 4",
+                         "limiter": "fp64 VALU issue (masker spreading + FFT + SPL conversions), not HBM -- DESIGN.md section 4",
                          "note": "dominant kernel by device time, priced against HBM as the contract asks; the "
                                  "HBM-bound kernel of the path is mdct_long_kernel, see kernels[0]"},
             "kernels": kernels,

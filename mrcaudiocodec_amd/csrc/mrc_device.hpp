@@ -24,6 +24,16 @@ __device__ __forceinline__ double load_signal(const double* __restrict__ L, cons
     return sig == 2 ? (l + r) / 2.0 : (l - r) / 2.0;
 }
 
+// MI355X: 8 XCDs, consecutive workgroup ids go to consecutive XCDs.  Maps hardware block id b of a 1-D grid of g
+// blocks to a work unit such that XCD x (the blocks with b % 8 == x) gets a contiguous range of units.  A bijection
+// for every g.
+constexpr unsigned kXcds = 8;
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned b, unsigned g) {
+    const unsigned x = b % kXcds, q = b / kXcds;
+    const unsigned base = g / kXcds, rem = g % kXcds;
+    return x * base + (x < rem ? x : rem) + q;
+}
+
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));

@@ -223,9 +223,12 @@ constexpr LogTabDev make_log_tab() {
 }
 __constant__ LogTabDev kLogTabDev = make_log_tab();
 
-// psychoac.py:8-12 with the table-driven log10 (mrc_log10.hpp); zero, denormal, inf and nan take the library path
+// psychoac.py:8-12 with the table-driven log10 (mrc_log10.hpp).  Anything below the smallest normal number -- zero,
+// denormals, negative values -- is more than 3000 dB under the -30 dB floor (a NaN ends there too, as with fmax in
+// spl_db); +inf stays +inf.
 __device__ __forceinline__ double spl_db_tab(double intensity, const double* __restrict__ tab) {
-    if (!(intensity >= 0x1p-1022 && intensity <= 0x1.fffffffffffffp+1023)) return spl_db(intensity);
+    if (!(intensity >= 0x1p-1022)) return -30.0;
+    if (intensity > 0x1.fffffffffffffp+1023) return intensity;
     return fmax(96 + 10 * log10_tab32(intensity, tab), -30.0);
 }
 
@@ -287,8 +290,13 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6;
     const int H = S.H, M = S.halfN;
-    const int64_t f = blockIdx.x / nsig;
-    const int sig = blockIdx.x % nsig;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so hardware block
+    // i + 1 runs on another die than block i.  Unit u below is chosen such that every XCD walks a CONTIGUOUS range of
+    // (frame, signal) units: neighbouring frames share a hop, and the four signals of a joint frame share all their
+    // samples -- with this order the second reader finds them in its own L2 instead of fetching them from HBM again.
+    const unsigned unit = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int64_t f = unit / nsig;
+    const int sig = unit % nsig;
     const int64_t off = offsets ? offsets[f] : f * stride;
     double2* A = (double2*)smem;                        // [H]
     double2* B = A + H;                                 // [H]
@@ -462,8 +470,8 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     // psychoac.py:214-217: SMR of a band = max over its lines of (SPL of the line - masked threshold),
     // accumulated with LDS integer max-atomics on an order-preserving key (initialised by the table
     // build's barrier below)
-    const int scale = oscale[blockIdx.x];
-    const double* X = lines + (int64_t)blockIdx.x * M;
+    const int scale = oscale[unit];
+    const double* X = lines + (int64_t)unit * M;
 
     if (EXACT) {
         for (int base = 0; base < M; base += kThreads * kLinesPerThread) {
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                 int k = base + tid + j * kThreads;
                 if (k < M) {
                     double thr = spl_db(tot[j]);                                 // psychoac.py:173
-                    if (thresh) thresh[(int64_t)blockIdx.x * M + k] = thr;
+                    if (thresh) thresh[(int64_t)unit * M + k] = thr;
                     double xs = ldexp(X[k], scale);                              // codecThem.py:323 (exact)
                     double spl = spl_db(2. * (xs * xs) / (1. / 2.)) - 6. * scale;   // psychoac.py:212
                     atomicMax(&bandKey[S.bandOfLine[k]], order_key(spl - thr));
@@ -714,7 +722,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
             // maskers more than 1/2 Bark above the line: -27 dB/Bark for all of them
             const double t = fma(cur.lowE, sc[cnt], tot);
             const double thr = spl_db_tab(t, logTab);                        // psychoac.py:173
-            if (thresh && k < M) thresh[(int64_t)blockIdx.x * M + k] = thr;
+            if (thresh && k < M) thresh[(int64_t)unit * M + k] = thr;
             const double xs = ldexp(cur.x, scale);                           // codecThem.py:323 (exact)
             const double spl = spl_db_tab(2. * (xs * xs) / (1. / 2.), logTab) - 6. * scale;      // psychoac.py:212
             const double ex = spl - thr;                 // lanes past the end repeat the last line: max unchanged
@@ -737,10 +745,10 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     __syncthreads();
     MRC_PHASE(11);
     for (int bnd = tid; bnd < S.nBands; bnd += kThreads) {
-        smr[(int64_t)blockIdx.x * S.nBands + bnd] = order_value(bandKey[bnd]);
+        smr[(int64_t)unit * S.nBands + bnd] = order_value(bandKey[bnd]);
         // max |X| per band of the UNSCALED lines: what the scale factors need (codecThem.py:346), so the back end
         // does not have to read the lines once more for it
-        if (bandPeak) bandPeak[(int64_t)blockIdx.x * S.nBands + bnd] = __longlong_as_double((long long)peakKey[bnd]);
+        if (bandPeak) bandPeak[(int64_t)unit * S.nBands + bnd] = __longlong_as_double((long long)peakKey[bnd]);
     }
 }
 

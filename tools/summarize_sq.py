@@ -2,7 +2,8 @@
 """
 SQ counter passes of tools/collect_counters.sh -> profiles/<tag>_sq_counters.json: per kernel the mean counter values
 per launch, VALU instructions per frame and the fraction of the VALU issue capacity in use (a wave64 VALU
-instruction occupies its SIMD for 4 cycles; 4 SIMDs x 256 CUs).
+instruction occupies its SIMD for 4 cycles; 4 SIMDs x 256 CUs = 1024 SIMDs; GRBM_GUI_ACTIVE as reported by rocprofv3
+on gfx950 is the SUM over the 8 XCDs, so the device runs GRBM_GUI_ACTIVE / 8 cycles).
 Usage: summarize_sq.py <tag> <frames_per_launch> [gpurun_out]
 """
 import collections, csv, glob, json, os, re, sys
@@ -32,6 +33,6 @@ for k, c in kern.items():
     if "SQ_INSTS_VALU" in c:
         c["valu_insts_per_frame"] = round(c["SQ_INSTS_VALU"] / frames, 1)
         if "GRBM_GUI_ACTIVE" in c:
-            c["valu_issue_frac_at_4cyc"] = round(c["SQ_INSTS_VALU"] * 4 / (c["GRBM_GUI_ACTIVE"] * 1024), 3)
+            c["valu_issue_frac_at_4cyc"] = round(c["SQ_INSTS_VALU"] * 4 / (c["GRBM_GUI_ACTIVE"] / 8 * 1024), 3)
 json.dump({"frames_per_launch": frames, "kernels": kern}, open(os.path.join(root, tag + "_sq_counters.json"), "w"), indent=1)
 print(json.dumps(kern.get("smr_kernel", {}), indent=1))
