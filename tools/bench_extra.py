@@ -125,3 +125,15 @@ dt = time.perf_counter() - t0
 assert (parsed["mantissa"] == o["mantissa"]).all()
 print(json.dumps({"workload": "host unpack_blocks (C++, 1 thread), huffman=True", "frames": n,
                   "Msamples_per_s": round(2 * n * 1024 / dt / 1e6, 1)}), flush=True)
+
+# ---- PCIe-inclusive rate of the per-block host API (mrc_encode_mono: pageable host buffers in, host buffers out)
+nb = 16384
+xb = noise((nb + 1) * 1024, 99).cpu().numpy()
+blocks = np.lib.stride_tricks.sliding_window_view(xb, 2048)[::1024][:nb].copy()
+enc.h.encode_mono(blocks[:256], 1024, 1024)
+t0 = time.perf_counter()
+enc.h.encode_mono(blocks, 1024, 1024)
+dt = time.perf_counter() - t0
+print(json.dumps({"workload": "host API mrc_encode_mono (explicit blocks from pageable host memory, outputs to host)",
+                  "frames": nb, "ms": round(dt * 1e3, 2), "Msamples_per_s": round(nb * 1024 / dt / 1e6, 1),
+                  "bytes_over_pcie_per_frame": 16384 + 4096 + 200 + 200 + 8}), flush=True)
