@@ -112,10 +112,19 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
+    # MRC_BENCH_BACKEND=gloo is a REHEARSAL mode for boxes with fewer GPUs than ranks (several ranks share a card,
+    # barrier and max-over-ranks go over gloo on the CPU); the driver's runs use the default, RCCL ("nccl").
+    backend = os.environ.get("MRC_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    coll_device = device if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     enc = StreamEncoder(device_id=local)
     F = args.frames
@@ -140,7 +149,7 @@ def main():
     torch.cuda.synchronize(device)
     elapsed = time.perf_counter() - t0
     barrier()
-    elapsed = max_over_ranks(elapsed, device)
+    elapsed = max_over_ranks(elapsed, coll_device)
 
     # per-kernel device time, hipEvents on the launch stream (outside the timed region)
     enc.h.set_timing(True)
