@@ -80,6 +80,8 @@ __device__ __forceinline__ double exp2_poly(double f) {
 // instructions per pair; max relative error ~3e-16.  s64*u == 0 gives exactly 1 (a line inside +-1/2 Bark gets
 // exactly the masker's intensity).  Requires |s64*u| < 2^31 (here it is < 16000).
 constexpr int kExpTab = 64;
+// an SPL reaches its -30 dB floor at an intensity of 10^-12.6 (psychoac.py:8-12); above this guard it does not
+constexpr double kSplFloorGuard = 1e-12;
 __device__ __forceinline__ double exp2_tab64(double s64, double u, const double* __restrict__ tab) {
     const double shifter = 0x1.8p52;
     const double tt = fma(s64, u, shifter);
@@ -316,6 +318,8 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     if (tid < kMaxBands) peakKey[tid] = 0ull;
     const double* zbS = smem + lay.zbOff;               // staged after the FFT (the area is FFT scratch / dead)
     const double* e2tab = smem + 2 * H - kExpTab;       // 2^(j/64): the tail of region A, behind the masker table
+    // per-band max of (line intensity / masked threshold) as the bit pattern of a positive double; in front of e2tab
+    unsigned long long* ratioKey = reinterpret_cast<unsigned long long*>(smem + 2 * H - kExpTab - kMaxBands);
     const double* logTab = smem + lay.logOff;
     // Hann window (window.py:28-45) and real FFT through an H = N/2 point complex FFT.  All global loads of a
     // thread are issued before the first use: one memory round trip per phase instead of one per iteration.
@@ -379,6 +383,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
         for (int k = tid; k < M; k += kThreads) zw[k] = S.zb[k];
         if (tid < kLogTabEntries * 4) smem[lay.logOff + tid] = kLogTabDev.v[tid];
         if (tid < kExpTab) smem[2 * H - kExpTab + tid] = kExp2Tab[tid];
+        if (tid < kMaxBands) ratioKey[tid] = 0ull;
     }
 
     // tonal maskers: strict 3-point peaks at bins p = 1 .. last-2, kept in increasing bin order.
@@ -721,21 +726,38 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
             }
             // maskers more than 1/2 Bark above the line: -27 dB/Bark for all of them
             const double t = fma(cur.lowE, sc[cnt], tot);
-            const double thr = spl_db_tab(t, logTab);                        // psychoac.py:173
-            if (thresh && k < M) thresh[(int64_t)unit * M + k] = thr;
+            // psychoac.py:173,212-217: SMR of a band = max over its lines of SPL(4 xs^2) - 6 scale - SPL(t).  Unless one
+            // of the two SPLs sits on its -30 dB floor (digital silence) that is 10 log10(4 xs^2 / t) - 6 scale, and
+            // log10 is monotone: the band maximum of the RATIO is taken and converted once per band at the end
+            // instead of two log10 per line (the difference to the reference's order of roundings is ~1e-14 dB, five
+            // orders below what the FFT in front of it already differs by).  Lines on the floor, and every line when
+            // the caller wants the thresholds themselves, take the reference's formula.
             const double xs = ldexp(cur.x, scale);                           // codecThem.py:323 (exact)
-            const double spl = spl_db_tab(2. * (xs * xs) / (1. / 2.), logTab) - 6. * scale;      // psychoac.py:212
-            const double ex = spl - thr;                 // lanes past the end repeat the last line: max unchanged
-            const int bnd = cur.bnd;
+            const double a2 = 2. * (xs * xs) / (1. / 2.);
+            const bool plain = thresh != nullptr || !(a2 >= kSplFloorGuard && t >= kSplFloorGuard);
+            double ex = -1e300, q = 0.0;
+            if (plain) {
+                const double thr = spl_db_tab(t, logTab);
+                if (thresh && k < M) thresh[(int64_t)unit * M + k] = thr;
+                ex = (spl_db_tab(a2, logTab) - 6. * scale) - thr;
+            } else {
+                q = a2 / t;
+            }
+            const int bnd = cur.bnd;                     // lanes past the end repeat the last line: maxima unchanged
             if (__all(bnd == __builtin_amdgcn_readfirstlane(bnd))) {
-                const double best = wave_max(ex);        // whole chunk inside one band (the wide top bands)
-                if (lane == 0) atomicMax(&bandKey[bnd], order_key(best));
+                const double qBest = wave_max(q);        // whole chunk inside one band (the wide top bands)
+                if (lane == 0) atomicMax(&ratioKey[bnd], (unsigned long long)__double_as_longlong(qBest));
+                if (__any(plain)) {
+                    const double best = wave_max(ex);
+                    if (lane == 0) atomicMax(&bandKey[bnd], order_key(best));
+                }
                 if (bandPeak) {
                     const double pk = wave_max(fabs(cur.x));
                     if (lane == 0) atomicMax(&peakKey[bnd], (unsigned long long)__double_as_longlong(pk));
                 }
             } else {
-                atomicMax(&bandKey[bnd], order_key(ex));
+                atomicMax(&ratioKey[bnd], (unsigned long long)__double_as_longlong(q));
+                if (plain) atomicMax(&bandKey[bnd], order_key(ex));
                 if (bandPeak) atomicMax(&peakKey[bnd], (unsigned long long)__double_as_longlong(fabs(cur.x)));
             }
             MRC_PHASE(10);
@@ -745,7 +767,12 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     __syncthreads();
     MRC_PHASE(11);
     for (int bnd = tid; bnd < S.nBands; bnd += kThreads) {
-        smr[(int64_t)unit * S.nBands + bnd] = order_value(bandKey[bnd]);
+        double v = bandKey[bnd] ? order_value(bandKey[bnd]) : -1e300;              // lines on the SPL floor / EXACT
+        if (!EXACT && ratioKey[bnd]) {
+            const double q = __longlong_as_double((long long)ratioKey[bnd]);
+            v = fmax(v, 10 * log10_tab32(q, logTab) - 6. * scale);
+        }
+        smr[(int64_t)unit * S.nBands + bnd] = v;
         // max |X| per band of the UNSCALED lines: what the scale factors need (codecThem.py:346), so the back end
         // does not have to read the lines once more for it
         if (bandPeak) bandPeak[(int64_t)unit * S.nBands + bnd] = __longlong_as_double((long long)peakKey[bnd]);
