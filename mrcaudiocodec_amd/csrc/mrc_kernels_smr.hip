@@ -234,6 +234,15 @@ __device__ __forceinline__ double spl_db_tab(double intensity, const double* __r
     return fmax(96 + 10 * log10_tab32(intensity, tab), -30.0);
 }
 
+// The reference's own per-line formula (psychoac.py:173,212), for lines whose SPL sits on the -30 dB floor and for
+// callers that want the thresholds.  Rare on the full path and deliberately OUT OF LINE: inlined, its constants would
+// be hoisted out of the sweep loop and cost registers (and scratch traffic) in every frame.
+__device__ __attribute__((noinline)) double excess_plain(double t, double a2, int scale, const double* tab, double* thrOut) {
+    const double thr = spl_db_tab(t, tab);
+    *thrOut = thr;
+    return (spl_db_tab(a2, tab) - 6. * scale) - thr;
+}
+
 // Where the staged tables sit in the dynamic LDS (offsets in doubles, chosen by launch_smr): the Bark grid of the
 // lines for the masker-side searches, the log10 table, the first quadrant of the FFT twiddles (-1: use global).
 struct SmrLds { int zbOff, logOff, twOff; };
@@ -737,9 +746,9 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
             const bool plain = thresh != nullptr || !(a2 >= kSplFloorGuard && t >= kSplFloorGuard);
             double ex = -1e300, q = 0.0;
             if (plain) {
-                const double thr = spl_db_tab(t, logTab);
+                double thr;
+                ex = excess_plain(t, a2, scale, logTab, &thr);
                 if (thresh && k < M) thresh[(int64_t)unit * M + k] = thr;
-                ex = (spl_db_tab(a2, logTab) - 6. * scale) - thr;
             } else {
                 q = a2 / t;
             }
