@@ -1,6 +1,7 @@
 // smr_kernel -- psychoac.py:134-219 on gfx950: Hann window -> real FFT -> intensity spectrum -> tonal
 // maskers (strict 3-point peaks, kept in bin order) -> masked threshold on the MDCT line grid ->
-// SMR per scale-factor band.  One 256-thread workgroup per (frame, signal), any block shape.
+// SMR per scale-factor band (and the per-band max |X| the scale factors need).  One 256-thread workgroup per
+// (frame, signal), any block shape; units are walked in an XCD-contiguous order.
 //
 // The cost is the spreading (psychoac.py:68-78,166-168): ~P maskers x N/2 lines of 10^x in float64
 // (P ~ 257, N/2 = 1024 on white noise).  Two evaluation modes:
@@ -8,17 +9,20 @@
 //  EXACT = true   the reference's expression, operation by operation, pow() per (masker, line), summed
 //                 in masker order.  ~200 fp64 instructions per pair.
 //  EXACT = false  (default) "sorted sweep".  Lines and maskers are both sorted in Bark, so for a line k
-//                 the maskers split into a prefix {z_m <= z_k + 1/2} and a suffix {z_m > z_k + 1/2}:
-//                   prefix: I_m * 2^(s_m * max(z_k - z_m - 1/2, 0)), s_m the level-dependent upper slope in
-//                           bits/Bark; one degree-11 polynomial 2^f per pair, exactly I_m inside +-1/2 Bark;
-//                   suffix: the lower slope is the same -27 dB/Bark for every masker, so the sum factors:
-//                           2^(-b(z_k+1/2)) * sum_{m in suffix} I_m 2^(b z_m), b = -2.7 log2(10): one table
-//                           value per line times a suffix sum over maskers (exponents carried in
-//                           double-double so the large cancelling exponents cost no accuracy).
-//                 ~20 fp64 instructions per pair that needs 2^x, one add per in-band pair, nothing per
-//                 suffix pair; each wave sweeps contiguous 64-line chunks with wave-uniform loop bounds.
-//                 Same integers as EXACT on every parity corpus, thresholds within 1e-10 dB
-//                 (tests/test_gpu_parity.py::test_spread_modes_agree).
+//                 the maskers split into three index ranges (found once per frame from the masker side):
+//                   more than 1/2 Bark below the line: I_m * 2^(s_m (z_k - z_m - 1/2)), s_m the level-dependent
+//                           upper slope.  FAR FIELD (maskers below every line of a 64-line chunk): expansion in
+//                           (slope - middle slope of the frame) x (distance from the chunk centre), one 2^x per
+//                           masker and chunk, order 8/12/16 chosen from a rigorous bound -- far_group().  NEAR
+//                           FIELD: one table-driven 2^x per pair (exp2_tab64, 16 instructions);
+//                   inside +-1/2 Bark: exactly I_m, as a difference of double-double prefix sums;
+//                   more than 1/2 Bark above: the lower slope is the same -27 dB/Bark for every masker, so the sum
+//                           factors into one table value per line times a suffix sum over maskers (exponents
+//                           carried in double-double).
+//                 The band maximum of SPL(line) - SPL(threshold) is taken on the RATIO of the two intensities and
+//                 converted with one log10 per band.  Same integers as EXACT on every parity corpus, thresholds
+//                 within 1e-10 dB (tests/test_gpu_parity.py::test_spread_modes_agree).
+// DESIGN.md section 4 has the derivations, the error bounds and the measured instruction counts.
 #include "mrc_device.hpp"
 #include "mrc_log10.hpp"
 
