@@ -57,6 +57,24 @@ def measured_traffic():
     return {k: v["hbm_bytes_per_frame"] for k, v in d["kernels"].items()}, os.path.basename(files[-1])
 
 
+def measured_valu():
+    """VALU instructions per frame and issue-capacity fraction of smr_kernel from the committed SQ counter summary
+    (profiles/*_sq_counters.json, tools/summarize_sq.py); None when there is none."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")),
+                   key=lambda f: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(f))])
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        k = json.load(f)["kernels"].get("smr_kernel", {})
+    if "valu_insts_per_frame" not in k:
+        return None
+    return {"valu_insts_per_frame": k["valu_insts_per_frame"], "issue_frac_of_peak": k.get("valu_issue_frac_at_4cyc"),
+            "source": os.path.basename(files[-1]),
+            "note": "wave64 fp64/int VALU instructions (4 cycles each on a SIMD, 1024 SIMDs): the roofline that binds this kernel"}
+
+
 def make_noise_stream(torch, device, n_frames, seed):
     """C2 content generated on the device: 16-bit Gaussian PCM mapped to signed fractions
     (pcmfile.py:91-100), one leading hop of zeros (priorBlock at file start)."""
@@ -192,6 +210,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[dom]["frac_hbm"],
                          "traffic": kernels[dom]["traffic"], "traffic_source": traffic_src,
                          "limiter": "fp64 VALU issue (masker spreading + FFT + SPL conversions), not HBM -- DESIGN.md section 4",
+                         "valu": measured_valu(),
                          "note": "dominant kernel by device time, priced against HBM as the contract asks; the "
                                  "HBM-bound kernel of the path is mdct_long_kernel, see kernels[0]"},
             "kernels": kernels,

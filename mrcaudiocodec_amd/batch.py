@@ -41,7 +41,7 @@ class StreamEncoder:
         return self._out[key]
 
     def encode(self, a, b, left, right, n_frames, frame_stride, offsets=None, reservoir_in=None, lines_out=None,
-               fresh=False):
+               fresh=False, offsets_checked=False):
         """Encode n_frames blocks of shape (a,b) read from device tensor(s) `left` (and `right` for joint stereo).
         Returns a dict of device tensors (reused between calls of the same size unless fresh=True)."""
         for t in (left, right, offsets, reservoir_in, lines_out):
@@ -49,9 +49,10 @@ class StreamEncoder:
                 raise ValueError("device-contiguous tensors expected")
         if left.dtype != torch.float64 or (right is not None and right.dtype != torch.float64):
             raise ValueError("PCM must be float64 signed fractions")
-        last = (offsets.max().item() if offsets is not None else (n_frames - 1) * frame_stride) + a + b
-        if n_frames > 0 and (left.numel() < last or (right is not None and right.numel() < last)):
-            raise ValueError("stream too short for %d frames" % n_frames)
+        if not (offsets is not None and offsets_checked):    # (reading offsets back synchronises with the device)
+            last = (offsets.max().item() if offsets is not None else (n_frames - 1) * frame_stride) + a + b
+            if n_frames > 0 and (left.numel() < last or (right is not None and right.numel() < last)):
+                raise ValueError("stream too short for %d frames" % n_frames)
         nb = len(self.h.bands(a, b))
         out = (self._alloc if fresh else self._outputs)(n_frames, right is not None, nb, (a + b) // 2)
         stream = torch.cuda.current_stream(self.device).cuda_stream
@@ -85,26 +86,38 @@ class StreamEncoder:
         is chained from block to block ON THE DEVICE (reservoir_out + Huffman bits_saved, codecThem.py:274,503),
         so there is no host round trip inside the loop.  Returns (steps, reservoir): steps = list of
         (stream ids (list), a, b, outputs dict of device tensors) in encode order; reservoir [nStreams] int32."""
+        import numpy as np
         nS, stride = left.shape[0], left.shape[1]
         if right.shape != left.shape or len(shapes) != nS:
             raise ValueError("left/right [nStreams][samples] and one shape list per stream expected")
         flatL, flatR = left.reshape(-1), right.reshape(-1)
         reservoir = torch.zeros((nS,), dtype=torch.int32, device=self.device)
+        # the schedule (which streams take which block shape at which step) is host logic on the shape lists: built
+        # with NumPy and uploaded BEFORE the loop, so the loop itself only queues kernels
+        nT = max((len(s) for s in shapes), default=0)
+        tab = np.full((nS, nT, 3), -1, dtype=np.int64)
+        for s, sh in enumerate(shapes):
+            if len(sh):
+                tab[s, :len(sh)] = np.asarray(sh, dtype=np.int64)
+        if nT and (tab[:, :, 0] + tab[:, :, 1] + tab[:, :, 2] > stride).any():
+            raise ValueError("a stream is too short for one of its blocks")
+        plan = []
+        for t in range(nT):
+            live = tab[:, t, 1] > 0
+            for (a, b) in sorted(set(map(tuple, tab[live, t, 1:3].tolist()))):
+                ids = np.nonzero(live & (tab[:, t, 1] == a) & (tab[:, t, 2] == b))[0]
+                plan.append((int(a), int(b), ids, ids * stride + tab[ids, t, 0]))
+        dev_plan = [(a, b, ids.tolist(), torch.from_numpy(ids).to(self.device), torch.from_numpy(offs).to(self.device))
+                    for (a, b, ids, offs) in plan]
         steps = []
-        for t in range(max((len(s) for s in shapes), default=0)):
-            groups = {}
-            for s in range(nS):
-                if t < len(shapes[s]):
-                    off, a, b = shapes[s][t]
-                    if off + a + b > stride:
-                        raise ValueError("stream %d is too short for its block %d" % (s, t))
-                    groups.setdefault((a, b), []).append((s, off))
-            for (a, b), members in sorted(groups.items()):
-                ids = [s for s, _ in members]
-                idx = torch.tensor(ids, dtype=torch.int64, device=self.device)
-                offs = torch.tensor([s * stride + off for s, off in members], dtype=torch.int64, device=self.device)
-                out = self.encode(a, b, flatL, flatR, len(ids), 0, offs, reservoir[idx].contiguous(), fresh=True)
-                _, _, nxt = self.huffman_gain(a, b, out, use_huffman)
+        for (a, b, ids, idx, offs) in dev_plan:
+            whole = len(ids) == nS                             # every stream takes this shape: no gather / scatter
+            out = self.encode(a, b, flatL, flatR, len(ids), 0, offs, reservoir if whole else reservoir[idx].contiguous(),
+                              fresh=True, offsets_checked=True)
+            _, _, nxt = self.huffman_gain(a, b, out, use_huffman)
+            if whole:
+                reservoir = nxt
+            else:
                 reservoir[idx] = nxt
-                steps.append((ids, a, b, out))
+            steps.append((ids, a, b, out))
         return steps, reservoir

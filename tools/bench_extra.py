@@ -137,3 +137,24 @@ dt = time.perf_counter() - t0
 print(json.dumps({"workload": "host API mrc_encode_mono (explicit blocks from pageable host memory, outputs to host)",
                   "frames": nb, "ms": round(dt * 1e3, 2), "Msamples_per_s": round(nb * 1024 / dt / 1e6, 1),
                   "bytes_over_pcie_per_frame": 16384 + 4096 + 200 + 200 + 8}), flush=True)
+
+# ---- stream mode: many stereo streams advance one block per step, bit reservoirs chained on the device
+nS, nT = 2048, 24
+gs = torch.Generator(device=dev)
+gs.manual_seed(7)
+pl = torch.clamp(torch.round(torch.randn((nS, (nT + 1) * 1024), generator=gs, device=dev, dtype=torch.float64) * 3000), -32767, 32767)
+sl = (torch.sign(pl) * 2.0 * torch.abs(pl) / 65535).contiguous()
+sl[:, :1024] = 0
+sr = (0.7 * sl + 0.3 * torch.roll(sl, 17, dims=1)).contiguous()
+sr[:, :1024] = 0
+shapes_all = [[(i * 1024, 1024, 1024) for i in range(nT)]] * nS
+enc.encode_chained(sl, sr, [s[:2] for s in shapes_all])          # warm-up
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+steps, reservoir = enc.encode_chained(sl, sr, shapes_all)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(json.dumps({"workload": "stream mode: %d stereo streams x %d chained joint blocks (Huffman pricing on device)" % (nS, nT),
+                  "ms_total": round(dt * 1e3, 2), "ms_per_step": round(dt * 1e3 / nT, 3),
+                  "Msamples_per_s": round(2 * nS * nT * 1024 / dt / 1e6, 1),
+                  "mean_final_reservoir_bits": round(float(reservoir.double().mean().item()), 1)}), flush=True)
