@@ -63,7 +63,7 @@ hipError_t launch_mdct(const DevShape& S, int64_t nFrames, const double* chL, co
 bool mdct_long_applicable(const DevShape& S, int64_t stride, const int64_t* offsets, const double* chL,
                           const double* chR);
 hipError_t launch_mdct_long(const DevShape& S, int64_t nFrames, const double* chL, const double* chR,
-                            int64_t stride, double* lines, int* oscale, hipStream_t st);
+                            int64_t stride, const int64_t* offsets, double* lines, int* oscale, hipStream_t st);
 hipError_t launch_window(const DevShape& S, int64_t nBlocks, const double* in, double* out, hipStream_t st);
 hipError_t launch_unscale(int64_t nBlocks, int halfN, const double* scaled, const int* oscale, double* lines,
                           hipStream_t st);

@@ -178,7 +178,7 @@ hipError_t launch_mdct(const DevShape& S, int64_t nFrames, const double* chL, co
                        const int64_t* offsets, bool applyWindow, double* lines, int* oscale, hipStream_t st) {
     if (nFrames <= 0) return hipSuccess;
     if (applyWindow && !(reinterpret_cast<uintptr_t>(lines) & 15) && mdct_long_applicable(S, stride, offsets, chL, chR))
-        return launch_mdct_long(S, nFrames, chL, chR, stride, lines, oscale, st);
+        return launch_mdct_long(S, nFrames, chL, chR, stride, offsets, lines, oscale, st);
     const int nsig = chR ? 4 : 1;
     size_t lds = (size_t)(2 * S.N) * sizeof(double);
     hipLaunchKernelGGL(mdct_kernel, dim3((unsigned)(nFrames * nsig)), dim3(kThreads), lds, st, S, nsig, chL, chR,

@@ -90,18 +90,25 @@ __device__ __forceinline__ int scale_factor20(double v, int nScaleBits) {       
     return lz < cap ? lz : cap;
 }
 
+// 16 bytes per lane when the sample offset is even (always, for strided layouts); an explicit offset may be odd,
+// then two 8-byte loads (wave-uniform choice)
+__device__ __forceinline__ double2 load2(const double* __restrict__ p, bool aligned) {
+    if (aligned) return *reinterpret_cast<const double2*>(p);
+    return make_double2(p[0], p[1]);
+}
+
 template <int NSIG>
 __device__ __forceinline__ void load_pair(const double* __restrict__ L, const double* __restrict__ R, int64_t i, int sig,
-                                          double* e, double* o) {
+                                          double* e, double* o, bool aligned = true) {
     if (NSIG == 1 || sig == 0) {
-        double2 v = *reinterpret_cast<const double2*>(L + i);
+        double2 v = load2(L + i, aligned);
         *e = v.x; *o = v.y;
     } else if (sig == 1) {
-        double2 v = *reinterpret_cast<const double2*>(R + i);
+        double2 v = load2(R + i, aligned);
         *e = v.x; *o = v.y;
     } else {
-        double2 l = *reinterpret_cast<const double2*>(L + i);
-        double2 r = *reinterpret_cast<const double2*>(R + i);
+        double2 l = load2(L + i, aligned);
+        double2 r = load2(R + i, aligned);
         if (sig == 2) { *e = (l.x + r.x) / 2.0; *o = (l.y + r.y) / 2.0; }       // codecThem.py:363
         else { *e = (l.x - r.x) / 2.0; *o = (l.y - r.y) / 2.0; }                // codecThem.py:364
     }
@@ -118,7 +125,7 @@ template <int R> __device__ __forceinline__ double2 twiddle_lane(double2 v, doub
 template <int NSIG, bool REUSE>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void mdct_long_kernel(
     DevShape S, int64_t nUnits, const double* __restrict__ chL, const double* __restrict__ chR, int64_t stride,
-    double* __restrict__ lines, int* __restrict__ oscale) {
+    const int64_t* __restrict__ offsets, double* __restrict__ lines, int* __restrict__ oscale) {
     __shared__ __attribute__((aligned(16))) double smem[kWavesPerBlock * kWaveLds + 2 * kQ];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x >> 6;
@@ -152,7 +159,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void mdct_long_kernel(
         if (unit >= nUnits) break;                                     // wave-uniform
         const int64_t f = NSIG == 1 ? unit : unit / NSIG;
         const int sig = NSIG == 1 ? 0 : (int)(unit % NSIG);
-        const int64_t off = f * stride;
+        const int64_t off = (!REUSE && offsets) ? offsets[f] : f * stride;
+        const bool aligned = REUSE || !(off & 1);
 
         // ---- A. coalesced load (16 B per lane), window, de-interleave into yE / yO
         double* yE = ws;
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void mdct_long_kernel(
             if (REUSE && c < 8) {
                 e = rawE[c]; o = rawO[c];
             } else {
-                load_pair<NSIG>(chL, chR, off + 2 * i, sig, &e, &o);
+                load_pair<NSIG>(chL, chR, off + 2 * i, sig, &e, &o, aligned);
                 if (REUSE) { rawE[c & 7] = e; rawO[c & 7] = o; }
             }
             yE[i] = e * wE[c];
@@ -242,14 +250,13 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void mdct_long_kernel(
 bool mdct_long_applicable(const DevShape& S, int64_t stride, const int64_t* offsets, const double* chL,
                           const double* chR) {
     if (S.a != 1024 || S.b != 1024) return false;
-    if (offsets) return false;                       // offsets may be odd: 16-byte loads need even sample offsets
-    if (stride % 2 != 0) return false;
+    if (!offsets && stride % 2 != 0) return false;   // (explicit offsets: the kernel checks each one's parity itself)
     if ((reinterpret_cast<uintptr_t>(chL) & 15) || (chR && (reinterpret_cast<uintptr_t>(chR) & 15))) return false;
     return true;
 }
 
 hipError_t launch_mdct_long(const DevShape& S, int64_t nFrames, const double* chL, const double* chR, int64_t stride,
-                            double* lines, int* oscale, hipStream_t st) {
+                            const int64_t* offsets, double* lines, int* oscale, hipStream_t st) {
     if (nFrames <= 0) return hipSuccess;
     const int nsig = chR ? 4 : 1;
     const int64_t nUnits = nFrames * nsig;
@@ -257,14 +264,14 @@ hipError_t launch_mdct_long(const DevShape& S, int64_t nFrames, const double* ch
     const unsigned grid = (unsigned)((nUnits + perBlock - 1) / perBlock);
     const dim3 block(kWave * kWavesPerBlock);
     if (nsig == 4)
-        hipLaunchKernelGGL((mdct_long_kernel<4, false>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, lines,
-                           oscale);
-    else if (stride == kM)                           // hop-overlapped stream: consecutive frames share a hop
-        hipLaunchKernelGGL((mdct_long_kernel<1, true>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, lines,
-                           oscale);
+        hipLaunchKernelGGL((mdct_long_kernel<4, false>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, offsets,
+                           lines, oscale);
+    else if (!offsets && stride == kM)               // hop-overlapped stream: consecutive frames share a hop
+        hipLaunchKernelGGL((mdct_long_kernel<1, true>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, offsets,
+                           lines, oscale);
     else
-        hipLaunchKernelGGL((mdct_long_kernel<1, false>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, lines,
-                           oscale);
+        hipLaunchKernelGGL((mdct_long_kernel<1, false>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, offsets,
+                           lines, oscale);
     return hipGetLastError();
 }
 

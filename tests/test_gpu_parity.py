@@ -414,3 +414,27 @@ def test_pac_bytes_many_streams_chained_on_device(h, huff):
         assert got[s] == want, s
     # and the single-stream driver gives the same bytes
     assert got[1] == ppac.encode_stereo_stream(h, streams[1], shapes[1], use_huffman=huff)
+
+
+def test_device_offsets_odd_and_even_long_blocks(h):
+    # explicit offsets into a device stream for LONG blocks (the wave-per-frame MDCT kernel): even offsets take
+    # 16-byte loads, odd ones the 8-byte path; mono and joint
+    torch = pytest.importorskip("torch")
+    from mrcaudiocodec_amd import synth
+    from mrcaudiocodec_amd.batch import StreamEncoder
+    x = synth.c2_noise(12, seed=21)
+    y = 0.6 * x + 0.4 * synth.c2_noise(12, seed=22)
+    offs = [0, 1, 2048, 3071, 4097, 5120, 9001, 10240]
+    enc = StreamEncoder(handle=h)
+    dx, dy = torch.from_numpy(x).to("cuda:0"), torch.from_numpy(y).to("cuda:0")
+    dev_offs = torch.tensor(offs, dtype=torch.int64, device="cuda:0")
+    bl = np.stack([x[o:o + 2048] for o in offs])
+    br = np.stack([y[o:o + 2048] for o in offs])
+    out = enc.encode(1024, 1024, dx, None, len(offs), 0, dev_offs)
+    ref = fast.encode_mono_batch(bl, 1024, 1024)
+    for k in _int_keys(False):
+        assert np.array_equal(out[k].cpu().numpy().reshape(np.asarray(ref[k]).shape), ref[k]), k
+    out = enc.encode(1024, 1024, dx, dy, len(offs), 0, dev_offs)
+    ref = fast.encode_joint_batch(bl, br, 1024, 1024)
+    for k in _int_keys(True):
+        assert np.array_equal(out[k].cpu().numpy().reshape(np.asarray(ref[k]).shape), ref[k]), k

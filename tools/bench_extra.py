@@ -69,8 +69,15 @@ def run_switched():
             enc.encode(a, b, x, None, o.numel(), 0, o)
 
 
+per_shape = {}
+for (a, b), o in offs.items():
+    enc.h.set_timing(True)
+    enc.encode(a, b, x, None, o.numel(), 0, o)
+    enc.encode(a, b, x, None, o.numel(), 0, o)
+    per_shape["%dx%d" % (a, b)] = {"blocks": int(o.numel()), "stage_ms_mdct_smr_backend": [round(float(v), 4) for v in enc.h.stage_ms()]}
+    enc.h.set_timing(False)
 dt = timed(run_switched)
-print(json.dumps({"workload": "configs[3] block switching (burst every 5th hop)", "hops": hops,
+print(json.dumps({"workload": "configs[3] block switching (burst every 5th hop)", "hops": hops, "per_shape": per_shape,
                   "blocks": {"%dx%d" % k: int(v.numel()) for k, v in offs.items()},
                   "ms_per_step": round(dt * 1e3, 3), "Msamples_per_s": round(hops * 1024 / dt / 1e6, 1)}), flush=True)
 
