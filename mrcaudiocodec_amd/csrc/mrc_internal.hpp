@@ -41,6 +41,9 @@ struct DevShape {
     const int* bandLo;               // [nBands]
     const int* bandN;                // [nBands]
     const unsigned char* bandOfLine; // [halfN]
+    const unsigned short* loLine;    // [halfN] first line j with zb[j] - zb[k] >= -1/2 (search hint)
+    const unsigned short* hiLine;    // [halfN] first line j with zb[j] - zb[k] > 1/2, halfN if none (search hint)
+    double linesPerHz;               // N / sampleRate
 };
 
 struct HostShape {

@@ -436,8 +436,10 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
             double s3 = (x0 + x1) + x2;
             double level = EXACT ? spl_db(s3) : spl_db_tab(s3, logTab);      // psychoac.py:164
             double fm = S.binHz * (((p - 1) * x0 + p * x1) + (p + 1) * x2) / s3;   // psychoac.py:165
-            double q = fm / 7500.;
-            const double zm = 13 * atan(0.76 * fm / 1000.) + 3.5 * atan(q * q);     // psychoac.py:27-29
+            // psychoac.py:27-29.  The fast path multiplies by the reciprocals of the constants 7500, 1000 and 10
+            // (one rounding more each, against ~12 instructions per fp64 division); EXACT divides like the reference
+            double q = EXACT ? fm / 7500. : fm * (1. / 7500.);
+            const double zm = 13 * atan(EXACT ? 0.76 * fm / 1000. : (0.76 * fm) * 1e-3) + 3.5 * atan(q * q);
             const double lvl15 = level - 15.0;                               // psychoac.py:42-43 (tonal drop)
             const double boost = 0.37 * fmax(level - 40, 0.0);               // psychoac.py:76
             double* e = mt + 4 * before;
@@ -447,29 +449,28 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                 e[2] = boost;
             } else {
                 // psychoac.py:14-18: 10^((spl-96)/10) as 2^(x log2 10), exponent in double-double (<= 1 ulp)
-                const double xe = (lvl15 - 96) / 10;
+                const double xe = (lvl15 - 96) * 0.1;
                 const double eh = xe * kLog2Of10;
                 const double I = exp2_dd(eh, fma(xe, kLog2Of10, -eh) + xe * kLog2Of10Lo);
                 const double ph = kLowHi * zm;
                 const double pl = fma(kLowHi, zm, -ph) + kLowLo * zm;
                 e[0] = I;
-                e[2] = (((-27 + boost) / 10) * kLog2Of10) * 64.0;          // upper slope, 1/64 bit per Bark
+                e[2] = (((-27 + boost) * 0.1) * kLog2Of10) * 64.0;         // upper slope, 1/64 bit per Bark
                 slLo = fmin(slLo, e[2]);
                 slHi = fmax(slHi, e[2]);
                 e[3] = I * exp2_dd(ph, pl);
                 // first line that sees this masker at all (fl(z_k - z_m) >= -1/2) and first line more than
                 // 1/2 Bark above it (fl(z_k - z_m) > 1/2): both predicates are monotone in k
-                int lo = 0, hi = M;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (zbS[mid] - zm >= -0.5) hi = mid; else lo = mid + 1;
-                }
+                // The searches start from the precomputed answers for the line nearest to the masker's own
+                // frequency and walk to the exact boundary (a step or two; any start gives the same result).
+                const int kNear = min(max((int)(fm * S.linesPerHz), 0), M - 1);
+                int lo = S.loLine[kNear], hi = S.hiLine[kNear];
+                while (lo > 0 && zbS[lo - 1] - zm >= -0.5) --lo;
+                while (lo < M && !(zbS[lo] - zm >= -0.5)) ++lo;
                 atomicAdd(reinterpret_cast<unsigned int*>(cntArr) + (lo >> 1), 1u << (16 * (lo & 1)));
-                hi = M;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (zbS[mid] - zm > 0.5) hi = mid; else lo = mid + 1;
-                }
+                lo = max(hi, lo);
+                while (lo > 0 && zbS[lo - 1] - zm > 0.5) --lo;
+                while (lo < M && !(zbS[lo] - zm > 0.5)) ++lo;
                 atomicAdd(reinterpret_cast<unsigned int*>(nUpArr) + (lo >> 1), 1u << (16 * (lo & 1)));
             }
         }

@@ -215,10 +215,22 @@ bool build_shape(const mrc_config& cfg, int a, int b, HostShape* out, std::strin
         lowE[k] = (double)powl(2.0L, lowBits * ((long double)zb[k] + 0.5L));
     }
 
+    // search hints for the masker-side line searches of smr_kernel: for a masker near line k the first line that
+    // sees it / the first line more than 1/2 Bark above it are close to these (the kernel fixes them up exactly)
+    std::vector<unsigned short> loLine(S.halfN), hiLine(S.halfN);
+    for (int k = 0, lo = 0, hi = 0; k < S.halfN; ++k) {
+        while (lo < S.halfN && !(zb[lo] - zb[k] >= -0.5)) ++lo;
+        while (hi < S.halfN && !(zb[hi] - zb[k] > 0.5)) ++hi;
+        loLine[k] = (unsigned short)lo;
+        hiLine[k] = (unsigned short)hi;
+    }
+    S.linesPerHz = (double)N / (double)cfg.sample_rate;       // line index ~ f * N/fs - 1/2
+
     BlobWriter bw;
     size_t oWin = bw.put(win), oHann = bw.put(hann), oPre = bw.put(pre), oPost = bw.put(post);
     size_t oWQ = bw.put(wQ), oWH = bw.put(wH), oWN = bw.put(wN), oZb = bw.put(zb), oQuiet = bw.put(quiet), oLowE = bw.put(lowE);
     size_t oLo = bw.put(out->bandLo), oCnt = bw.put(out->bandN), oBol = bw.put(bandOfLine);
+    size_t oLoLine = bw.put(loLine), oHiLine = bw.put(hiLine);
     void* blob = nullptr;
     if (hipMalloc(&blob, bw.bytes.size()) != hipSuccess) { *err = "hipMalloc(shape tables) failed"; return false; }
     if (hipMemcpy(blob, bw.bytes.data(), bw.bytes.size(), hipMemcpyHostToDevice) != hipSuccess) {
@@ -235,6 +247,8 @@ bool build_shape(const mrc_config& cfg, int a, int b, HostShape* out, std::strin
     S.lowE = (const double*)(base + oLowE);
     S.bandLo = (const int*)(base + oLo);        S.bandN = (const int*)(base + oCnt);
     S.bandOfLine = (const unsigned char*)(base + oBol);
+    S.loLine = (const unsigned short*)(base + oLoLine);
+    S.hiLine = (const unsigned short*)(base + oHiLine);
     out->blob = blob;
     return true;
 }
