@@ -15,6 +15,8 @@ namespace mrc {
 using namespace dev;
 namespace {
 
+constexpr int kBandLds = 2048;                          // lines per block whose band map quantize_kernel stages in LDS
+
 // ------------------------------------------------------------------------------------------------
 // band statistics: one wavefront per frame
 // ------------------------------------------------------------------------------------------------
@@ -158,7 +160,8 @@ __global__ __launch_bounds__(kWave) void quantize_kernel(DevShape S, int joint, 
                                                          const int* __restrict__ msSwitch,
                                                          const int* __restrict__ bitAlloc,
                                                          int* __restrict__ scaleFactor, int* __restrict__ mantissa) {
-    __shared__ int sBa[kMaxBands], sSf[kMaxBands], sSig[kMaxBands];
+    __shared__ int sBa[kMaxBands], sSf[kMaxBands], sSig[kMaxBands], sOsc[kMaxBands];
+    __shared__ unsigned char sBand[kBandLds];            // band of every line (copy of S.bandOfLine)
     const int lane = threadIdx.x;
     const int nstream = joint ? 2 : 1, nsig = joint ? 4 : 1;
     const int64_t f = blockIdx.x / nstream;
@@ -166,6 +169,12 @@ __global__ __launch_bounds__(kWave) void quantize_kernel(DevShape S, int joint, 
     const int M = S.halfN, nb = S.nBands;
     const double* X = lines + f * nsig * M;
     const int* osc = oscale + f * nsig;
+    // the line -> band map goes to LDS with the other per-band values: the loop below then has ONE global round
+    // trip per batch of lines (the lines themselves) instead of two dependent ones per line
+    const bool bandInLds = M <= kBandLds;
+    if (bandInLds)
+        for (int k = 4 * lane; k < M; k += 4 * kWave)
+            *reinterpret_cast<unsigned int*>(sBand + k) = *reinterpret_cast<const unsigned int*>(S.bandOfLine + k);
     if (lane < nb) {
         const int sig = joint ? (msSwitch[f * nb + lane] ? 2 + strm : strm) : 0;
         const int ba = bitAlloc[(f * nstream + strm) * nb + lane];
@@ -176,19 +185,31 @@ __global__ __launch_bounds__(kWave) void quantize_kernel(DevShape S, int joint, 
         sBa[lane] = ba;
         sSf[lane] = sf;
         sSig[lane] = sig;
+        sOsc[lane] = osc[sig];
         scaleFactor[(f * nstream + strm) * nb + lane] = sf;
     }
     __syncthreads();
     int* out = mantissa + (f * nstream + strm) * M;
-    for (int k = lane; k < M; k += kWave) {
-        const int bnd = S.bandOfLine[k];
-        const int ba = sBa[bnd];
-        int m = 0;
-        if (ba) {
-            const int sg = sSig[bnd];
-            m = mantissa_dev(ldexp(X[sg * M + k], osc[sg]), sSf[bnd], S.nScaleBits, ba);   // codecThem.py:348-349
+    constexpr int kBatch = 4;                            // lines in flight per lane
+    for (int k0 = lane; k0 < M; k0 += kWave * kBatch) {
+        int bnd[kBatch], sc[kBatch];
+        double x[kBatch];
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int k = min(k0 + u * kWave, M - 1);
+            bnd[u] = bandInLds ? sBand[k] : S.bandOfLine[k];
+            const int sg = sSig[bnd[u]];
+            sc[u] = sOsc[bnd[u]];
+            x[u] = sBa[bnd[u]] ? X[sg * M + k] : 0.0;       // lines of bands without bits are not even read
         }
-        out[k] = m;
+#pragma unroll
+        for (int u = 0; u < kBatch; ++u) {
+            const int k = k0 + u * kWave;
+            if (k < M) {
+                const int ba = sBa[bnd[u]];
+                out[k] = ba ? mantissa_dev(ldexp(x[u], sc[u]), sSf[bnd[u]], S.nScaleBits, ba) : 0;   // codecThem.py:348-349
+            }
+        }
     }
 }
 
