@@ -141,35 +141,30 @@ __device__ __forceinline__ void dd_add(double* hi, double* lo, double xh, double
 // remaining values to its partner and adds the partner's half of the others (W/2 + W/4 + ... + 1 exchanges instead
 // of W x 6); plain butterfly steps finish the one value left per lane and W broadcasts distribute the totals.
 // Values beyond the last full block are reduced one by one.
+// one exchange of the transposing butterfly: the lane keeps `mine`, hands `other` to its partner at distance DIST
+template <int DIST>
+__device__ __forceinline__ double wave_xchg_add(double a, double b, bool hi) {
+    const double send = hi ? a : b;
+    const double keep = hi ? b : a;
+    return keep + __shfl_xor(send, DIST);
+}
+
+// W = 8 values (written out: a loop over the halving steps makes the compiler index the temporaries dynamically)
 template <int W>
 __device__ __forceinline__ void wave_sum_block(double* v, int lane) {
-    static_assert(W == 16 || W == 8, "block of 16 or 8 values");
-    double w[W / 2];
-    int dist = 32;
-    {
-        const bool hi = lane & dist;
-#pragma unroll
-        for (int i = 0; i < W / 2; ++i) {
-            const double send = hi ? v[i] : v[i + W / 2];
-            const double keep = hi ? v[i + W / 2] : v[i];
-            w[i] = keep + __shfl_xor(send, dist);
-        }
-    }
-#pragma unroll
-    for (int n = W / 4; n >= 1; n >>= 1) {
-        dist >>= 1;
-        const bool hi = lane & dist;
-#pragma unroll
-        for (int i = 0; i < n; ++i) {
-            const double send = hi ? w[i] : w[i + n];
-            const double keep = hi ? w[i + n] : w[i];
-            w[i] = keep + __shfl_xor(send, dist);
-        }
-    }
-    double s = w[0];
-#pragma unroll
-    for (int d = dist >> 1; d >= 1; d >>= 1) s += __shfl_xor(s, d);
-    // the lane whose top log2(W) bits spell j (most significant first) holds the total of value j
+    static_assert(W == 8, "block of 8 values");
+    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+    const double a0 = wave_xchg_add<32>(v[0], v[4], h5);       // lanes with bit 5 clear keep values 0..3, the others 4..7
+    const double a1 = wave_xchg_add<32>(v[1], v[5], h5);
+    const double a2 = wave_xchg_add<32>(v[2], v[6], h5);
+    const double a3 = wave_xchg_add<32>(v[3], v[7], h5);
+    const double b0 = wave_xchg_add<16>(a0, a2, h4);
+    const double b1 = wave_xchg_add<16>(a1, a3, h4);
+    double s = wave_xchg_add<8>(b0, b1, h3);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 1);
+    // the lane whose top three bits spell j (most significant first) holds the total of value j
 #pragma unroll
     for (int j = 0; j < W; ++j) v[j] = __shfl(s, j * (kWave / W));
 }
