@@ -267,6 +267,11 @@ __device__ unsigned long long gPhaseCycles[16];
 #else
 #define MRC_PHASE(i) do { } while (0)
 #endif
+#ifdef MRC_PROFILE_STOP                         // profiling aid: leave the kernel after phase MRC_PROFILE_STOP
+#define MRC_STOP(i) do { if (MRC_PROFILE_STOP == (i)) return; } while (0)
+#else
+#define MRC_STOP(i) do { } while (0)
+#endif
 
 #ifndef MRC_SMR_WAVES_PER_EU                     // 4 workgroups of 4 waves per CU (what the LDS footprint allows): <= 128 VGPRs
 #define MRC_SMR_WAVES_PER_EU 4
@@ -355,14 +360,14 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
         double2* Wq = reinterpret_cast<double2*>(smem + lay.twOff);
         for (int t = tid; t < H / 4; t += kThreads) Wq[t] = S.wH[t];
         __syncthreads();
-        MRC_PHASE(0);
+        MRC_PHASE(0); MRC_STOP(0);
         T = fft_lds_pow2(A, B, H, S.radH, S.nRadH, TwQuarter{Wq, H / 4 - 1, 31 - __clz(H / 4)}, tid);
     } else {
         __syncthreads();
-        MRC_PHASE(0);
+        MRC_PHASE(0); MRC_STOP(0);
         T = fft_lds(A, B, H, S.radH, S.nRadH, S.wH, tid);
     }
-    MRC_PHASE(1);
+    MRC_PHASE(1); MRC_STOP(1);
     for (int k0 = tid; k0 < last; k0 += kThreads * kPre) {
         double2 wn[kPre];
 #pragma unroll
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
         }
     }
     __syncthreads();                                    // T (in A or B) is dead from here on
-    MRC_PHASE(2);
+    MRC_PHASE(2); MRC_STOP(2);
     if (!EXACT) {                                       // stage the Bark grid and the log10 table (used after 2 barriers)
         double* zw = smem + lay.zbOff;
         for (int k = tid; k < M; k += kThreads) zw[k] = S.zb[k];
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     if (!EXACT)
         for (int k = tid; k <= M; k += kThreads) { cntArr[k] = 0; nUpArr[k] = 0; }
     __syncthreads();
-    MRC_PHASE(3);
+    MRC_PHASE(3); MRC_STOP(3);
     double slLo = 1e300, slHi = -1e300;                 // this thread's maskers: range of the upper slope
     for (int mi = tid; mi < nPeaks; mi += kThreads) {
         const int p = pkBin[mi];
@@ -479,7 +484,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
         }
     }
     __syncthreads();
-    MRC_PHASE(4);
+    MRC_PHASE(4); MRC_STOP(4);
 
     // psychoac.py:214-217: SMR of a band = max over its lines of (SPL of the line - masked threshold),
     // accumulated with LDS integer max-atomics on an order-preserving key (initialised by the table
@@ -598,7 +603,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
             }
         }
         __syncthreads();
-        MRC_PHASE(5);
+        MRC_PHASE(5); MRC_STOP(5);
 
         // Each wave sweeps 64-line chunks (one line per lane); the chunk order pairs cheap (low) with
         // expensive (high) chunks so the four waves finish together.  Per line, the Bark-sorted maskers
