@@ -148,3 +148,30 @@ def test_round_trip_on_device_at_scale(h):
     ref, dec = stream[:, 2048:(hops - 1) * 1024], x[:, 2048:(hops - 1) * 1024]
     snr = 10 * np.log10((ref ** 2).sum() / ((dec - ref) ** 2).sum())
     assert snr > 60, snr
+
+
+def test_decode_mono_pac_file(h):
+    # a one-channel file (header + WriteDataBlock chunks, pacfileThem.py:622-790): every block through the non-joint
+    # reader; raw and Huffman-coded
+    pytest.importorskip("torch")
+    from mrcaudiocodec_amd import pacfile as ppac, synth
+    hops = 9
+    cfg = ppac.make_config()
+    for huff in (False, True):
+        # noise never lets a Huffman table win: the coded case is a pure tone
+        x = synth.c1_sine(hops) + (0.0 if huff else 1.0) * synth.c2_noise(hops, seed=4, sigma=0.01)
+        blocks = np.array(fast.blocks_from_stream(x, 1024))
+        enc = h.encode_mono(blocks, 1024, 1024)
+        data, _, table, _ = ppac.pack_blocks(cfg, 1024, 1024, enc["overall_scale"][:, None], enc["scale_factor"][:, None, :],
+                                             enc["bit_alloc"][:, None, :], enc["mantissa"][:, None, :], huff)
+        pac = ppac.header(cfg, 1, len(blocks) * 1024) + data.tobytes()
+        cp, want = odec.decode_pac(pac)
+        nch, got = ppac.decode_pac(h, pac)
+        got = got.cpu().numpy()
+        assert nch == 1 and cp.nChannels == 1 and got.shape == want.shape == (1, (len(blocks) + 1) * 1024)
+        assert np.max(np.abs(got - want)) <= 1e-12 * np.max(np.abs(want))
+        ref = x[1024:len(blocks) * 1024]
+        snr = 10 * np.log10((ref ** 2).sum() / ((got[0, 1024:len(blocks) * 1024] - ref) ** 2).sum())
+        assert snr > 15, snr
+        if huff:
+            assert (table != 15).any()
