@@ -355,6 +355,19 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     }
     const int last = S.peakLast;                        // bins 0 .. last-1 are inspected (psychoac.py:160)
     const double xiInv = 1.0 / S.xiDen;
+    // Constants that are only needed after the FFT are requested BEFORE it (their LDS homes are FFT scratch until
+    // then): the loads complete under the FFT's barriers instead of adding a memory round trip of their own.
+    double2 wnPre[kPre];
+    double zbPre[kPre], logPre = 0.0, e2Pre = 0.0;
+#pragma unroll
+    for (int u = 0; u < kPre; ++u) {
+        wnPre[u] = S.wN[min(tid + u * kThreads, last - 1)];
+        zbPre[u] = EXACT ? 0.0 : S.zb[min(tid + u * kThreads, M - 1)];
+    }
+    if (!EXACT) {
+        logPre = kLogTabDev.v[tid & (kLogTabEntries * 4 - 1)];
+        e2Pre = kExp2Tab[tid & (kExpTab - 1)];
+    }
     double2* T;
     if (lay.twOff >= 0) {
         double2* Wq = reinterpret_cast<double2*>(smem + lay.twOff);
@@ -371,7 +384,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     for (int k0 = tid; k0 < last; k0 += kThreads * kPre) {
         double2 wn[kPre];
 #pragma unroll
-        for (int u = 0; u < kPre; ++u) wn[u] = S.wN[min(k0 + u * kThreads, last - 1)];
+        for (int u = 0; u < kPre; ++u) wn[u] = (k0 == tid) ? wnPre[u] : S.wN[min(k0 + u * kThreads, last - 1)];
 #pragma unroll
         for (int u = 0; u < kPre; ++u) {
             const int k = k0 + u * kThreads;
@@ -393,9 +406,12 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     MRC_PHASE(2); MRC_STOP(2);
     if (!EXACT) {                                       // stage the Bark grid and the log10 table (used after 2 barriers)
         double* zw = smem + lay.zbOff;
-        for (int k = tid; k < M; k += kThreads) zw[k] = S.zb[k];
-        if (tid < kLogTabEntries * 4) smem[lay.logOff + tid] = kLogTabDev.v[tid];
-        if (tid < kExpTab) smem[2 * H - kExpTab + tid] = kExp2Tab[tid];
+#pragma unroll
+        for (int u = 0; u < kPre; ++u)
+            if (tid + u * kThreads < M) zw[tid + u * kThreads] = zbPre[u];
+        for (int k = tid + kPre * kThreads; k < M; k += kThreads) zw[k] = S.zb[k];
+        if (tid < kLogTabEntries * 4) smem[lay.logOff + tid] = logPre;
+        if (tid < kExpTab) smem[2 * H - kExpTab + tid] = e2Pre;
         if (tid < kMaxBands) ratioKey[tid] = 0ull;
     }
 
