@@ -282,6 +282,12 @@ __device__ unsigned long long gPhaseCycles[16];
 #define MRC_SMR_OCC
 #endif
 
+#ifndef MRC_FRONT_PRIO                           // issue priority (0..3) of a wave until it enters the sweep
+#define MRC_FRONT_PRIO 3
+#endif
+#ifndef MRC_FAR_PRIO                             // ... and during the far-field pass (shuffle-heavy reductions)
+#define MRC_FAR_PRIO 0
+#endif
 #ifndef MRC_DIRECT_UNROLL                        // pairs in flight per lane in the direct loops
 #define MRC_DIRECT_UNROLL 4
 #endif
@@ -326,6 +332,10 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
 #ifdef MRC_PROFILE_PHASES
     long long tPhase_ = clock64();
 #endif
+    // The phases before the sweep are chains of short instruction bursts between barriers and memory waits; the sweep
+    // is one long stream of VALU work.  Waves of the four workgroups that share a SIMD are in different phases: the
+    // ones in the latency-bound part get issue priority, so their chain is not stretched by a neighbour's sweep.
+    __builtin_amdgcn_s_setprio(MRC_FRONT_PRIO);
     if (tid < kMaxBands) bandKey[tid] = 0ull;           // below every key; visible after the first barrier
     if (tid < 2) slopeKey[tid] = tid ? 0ull : ~0ull;
     if (tid < kMaxBands) peakKey[tid] = 0ull;
@@ -637,6 +647,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
             const int kc = min(chunk_of(i) * kWave + lane, M - 1);
             return LineConst{S.zb[kc], S.quiet[kc], S.lowE[kc], X[kc], S.bandOfLine[kc]};
         };
+        __builtin_amdgcn_s_setprio(0);
         const double slMid = 0.5 * (order_value(slopeKey[0]) + order_value(slopeKey[1]));
         const double spreadHalf = 0.5 * (order_value(slopeKey[1]) - order_value(slopeKey[0])) * (0.6931471805599453094 / 64.0);
         // Rounds of up to four chunks per wave.  Pass 1 evaluates the FAR FIELD of the round's chunks -- the only part
@@ -649,6 +660,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
         // half the slope range times half the Bark span, so a frame of similar maskers (noise) gets by with a low
         // order even where 64 lines span more than a Bark, and a frame with a loud and a quiet region still
         // qualifies at the top of the spectrum.  The truncated tail is < 1e-17 of each term.
+        __builtin_amdgcn_s_setprio(MRC_FAR_PRIO);
         double far0 = 0.0, far1 = 0.0, far2 = 0.0, far3 = 0.0;
         unsigned farMask = 0;                            // bit u: chunk u of the round took the far field
         for (int u = 0; u < 4; ++u) {
@@ -696,6 +708,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
         MRC_PHASE(7);
         // ---- pass 2.  The per-line constants of the NEXT chunk are loaded while this one is computed (loop-carried,
         // so the global-load latency is never exposed between the loops of a chunk)
+        __builtin_amdgcn_s_setprio(0);
         LineConst nxt = load_consts(i0);
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + u;
