@@ -609,23 +609,19 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                 }
             }
         }
-        // per-line masker counts: inclusive prefix sums of the two histograms the table build left
-        // (cnt[k] = maskers with fl(z_k - z_m) >= -1/2, nUp[k] = maskers with fl(z_k - z_m) > 1/2)
-        {
-            const int per2 = (M + kThreads) / kThreads;                     // entries per thread, covers 0..M
-            const int k0 = tid * per2, k1 = min(k0 + per2, M + 1);
-            unsigned int sc2 = 0, su2 = 0;
-            for (int k = k0; k < k1; ++k) { sc2 += cntArr[k]; su2 += nUpArr[k]; }
-            unsigned int packed = sc2 | (su2 << 16);                         // both sums < 2^16
-            const unsigned int inclP = (unsigned int)wave_incl_scan((int)packed, lane);
-            if (lane == kWave - 1) waveCnt[wave] = (int)inclP;
-            __syncthreads();
-            unsigned int base = inclP - packed;
-            for (int w = 0; w < wave; ++w) base += (unsigned int)waveCnt[w];
-            unsigned int rc = base & 0xffffu, ru = base >> 16;
+        else {
+            // waves 2 and 3 -- per-line masker counts: inclusive prefix sums of the two histograms the table build left
+            // (cnt[k] = maskers with fl(z_k - z_m) >= -1/2, nUp[k] = maskers with fl(z_k - z_m) > 1/2), one array per
+            // wave, so the three scans of this phase run side by side and share one barrier
+            unsigned short* arr = (wave == 2) ? cntArr : nUpArr;
+            const int per2 = (M + kWave) / kWave;                            // entries per lane, covers 0..M
+            const int k0 = lane * per2, k1 = min(k0 + per2, M + 1);
+            int sum = 0;
+            for (int k = k0; k < k1; ++k) sum += arr[k];
+            int run = wave_incl_scan(sum, lane) - sum;
             for (int k = k0; k < k1; ++k) {
-                rc += cntArr[k]; ru += nUpArr[k];
-                cntArr[k] = (unsigned short)rc; nUpArr[k] = (unsigned short)ru;
+                run += arr[k];
+                arr[k] = (unsigned short)run;
             }
         }
         __syncthreads();
