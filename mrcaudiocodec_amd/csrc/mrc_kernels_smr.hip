@@ -638,7 +638,8 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
         // the per-line constants of the NEXT chunk are loaded while this one is computed (loop-carried, so the
         // global-load latency is never exposed between the loops of a chunk)
         struct LineConst { double z, quiet, lowE, x; int bnd; };
-        auto chunk_of = [&](int i) { return i * nWaves + ((i & 1) ? (nWaves - 1 - wave) : wave); };
+        const int waveU = __builtin_amdgcn_readfirstlane(wave);          // (uniform: chunk indices stay in SGPRs)
+        auto chunk_of = [&](int i) { return i * nWaves + ((i & 1) ? (nWaves - 1 - waveU) : waveU); };
         auto load_consts = [&](int i) {
             const int kc = min(chunk_of(i) * kWave + lane, M - 1);
             return LineConst{S.zb[kc], S.quiet[kc], S.lowE[kc], X[kc], S.bandOfLine[kc]};
@@ -666,8 +667,10 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
             const int nFar = __builtin_amdgcn_readfirstlane((int)nUpArr[kc]);      // nUp of the chunk's first line
             if (nFar < kFarMinMaskers || (MRC_PROFILE_SKIP & 1)) continue;
             const double z = S.zb[kc];
-            const double zFirst = __shfl(z, 0), zLast = __shfl(z, kWave - 1);
-            const double zHalfEnd = __shfl(z, kWave / 2 - 1), zHalfBeg = __shfl(z, kWave / 2);
+            // the group geometry is wave-uniform: scalar loads of the chunk's first / middle / last Bark values
+            const int kFirst = c * kWave;
+            const double zFirst = S.zb[kFirst], zLast = S.zb[min(kFirst + kWave - 1, M - 1)];
+            const double zHalfEnd = S.zb[min(kFirst + kWave / 2 - 1, M - 1)], zHalfBeg = S.zb[min(kFirst + kWave / 2, M - 1)];
             const double need1 = spreadHalf * (0.5 * (zLast - zFirst));
             const double need2 = spreadHalf * (0.5 * fmax(zHalfEnd - zFirst, zLast - zHalfBeg));
             double need = need1;
