@@ -141,32 +141,53 @@ __device__ __forceinline__ void dd_add(double* hi, double* lo, double xh, double
 // remaining values to its partner and adds the partner's half of the others (W/2 + W/4 + ... + 1 exchanges instead
 // of W x 6); plain butterfly steps finish the one value left per lane and W broadcasts distribute the totals.
 // Values beyond the last full block are reduced one by one.
-// one exchange of the transposing butterfly: the lane keeps `mine`, hands `other` to its partner at distance DIST
+// Cross-lane primitives of the coefficient reduction, all register-to-register (no LDS round trips):
+//   distance 32 / 16: gfx950's v_permlane32_swap / v_permlane16_swap exchange the upper half (odd 16-lane rows) of one
+//                     register with the lower half (even rows) of another -- exactly one step of a transposing
+//                     butterfly: afterwards the lower lanes hold both halves' `a`, the upper lanes both halves' `b`;
+//   distance 8, 4, 2, 1: DPP row rotate / half mirror / quad permutes.
+typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
 template <int DIST>
-__device__ __forceinline__ double wave_xchg_add(double a, double b, bool hi) {
-    const double send = hi ? a : b;
-    const double keep = hi ? b : a;
-    return keep + __shfl_xor(send, DIST);
+__device__ __forceinline__ double wave_xchg_add(double a, double b) {
+    static_assert(DIST == 32 || DIST == 16, "swap distance");
+    const unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+    const unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+    const uint2v lo = DIST == 32 ? __builtin_amdgcn_permlane32_swap(alo, blo, false, false)
+                                 : __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    const uint2v hi = DIST == 32 ? __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false)
+                                 : __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
 
-// W = 8 values (written out: a loop over the halving steps makes the compiler index the temporaries dynamically)
+// Sum each of 8 per-lane values over the 64 lanes of the wave and leave the 8 totals in every lane (wave-uniform).
+// Transposing butterfly: at distances 32, 16, 8 a lane hands HALF of its remaining values to its partner and adds
+// the partner's half of the others (4 + 2 + 1 exchanges instead of 8 x 6); three plain steps finish the one value
+// left per lane; the lane group [8j, 8j+8) then holds the total of value j.
 template <int W>
 __device__ __forceinline__ void wave_sum_block(double* v, int lane) {
     static_assert(W == 8, "block of 8 values");
-    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
-    const double a0 = wave_xchg_add<32>(v[0], v[4], h5);       // lanes with bit 5 clear keep values 0..3, the others 4..7
-    const double a1 = wave_xchg_add<32>(v[1], v[5], h5);
-    const double a2 = wave_xchg_add<32>(v[2], v[6], h5);
-    const double a3 = wave_xchg_add<32>(v[3], v[7], h5);
-    const double b0 = wave_xchg_add<16>(a0, a2, h4);
-    const double b1 = wave_xchg_add<16>(a1, a3, h4);
-    double s = wave_xchg_add<8>(b0, b1, h3);
-    s += __shfl_xor(s, 4);
-    s += __shfl_xor(s, 2);
-    s += __shfl_xor(s, 1);
-    // the lane whose top three bits spell j (most significant first) holds the total of value j
+    const double a0 = wave_xchg_add<32>(v[0], v[4]);           // lanes 0..31 keep values 0..3, lanes 32..63 values 4..7
+    const double a1 = wave_xchg_add<32>(v[1], v[5]);
+    const double a2 = wave_xchg_add<32>(v[2], v[6]);
+    const double a3 = wave_xchg_add<32>(v[3], v[7]);
+    const double b0 = wave_xchg_add<16>(a0, a2);               // even rows keep the lower pair, odd rows the upper
+    const double b1 = wave_xchg_add<16>(a1, a3);
+    const double s0 = b0 + dpp_move<0x128>(b0);                // row_ror:8 = lane ^ 8
+    const double s1 = b1 + dpp_move<0x128>(b1);
+    double s = (lane & 8) ? s1 : s0;
+    s += dpp_move<0xB1>(s);                                    // quad_perm [1,0,3,2]
+    s += dpp_move<0x4E>(s);                                    // quad_perm [2,3,0,1]
+    s += dpp_move<0x141>(s);                                   // row_half_mirror: the other quad of the 8-lane group
 #pragma unroll
-    for (int j = 0; j < W; ++j) v[j] = __shfl(s, j * (kWave / W));
+    for (int j = 0; j < W; ++j)
+        v[j] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(s), j * (kWave / W)),
+                                __builtin_amdgcn_readlane(__double2loint(s), j * (kWave / W)));
 }
 
 // blocks of 8 only: a block of 16 would save three exchanges per 16 values but keeps 24 doubles live at once
