@@ -34,10 +34,41 @@ __device__ __forceinline__ unsigned xcd_contiguous(unsigned b, unsigned g) {
     return x * base + (x < rem ? x : rem) + q;
 }
 
+// ---- cross-lane reductions that stay in registers (no ds_bpermute: the LDS pipe is busy enough).  All 64 lanes
+// must be active.  Within a 16-lane row: DPP quad permutes, half mirror, rotate by 8.  Across rows: gfx950's
+// v_permlane16_swap / v_permlane32_swap exchange the odd rows (upper half) of one register with the even rows
+// (lower half) of another; swapping a value with itself leaves {even, even} and {odd, odd} copies to combine.
+typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int DIST, class Op>
+__device__ __forceinline__ double rows_combine(double v, Op op) {
+    static_assert(DIST == 32 || DIST == 16, "swap distance");
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const uint2v l = DIST == 32 ? __builtin_amdgcn_permlane32_swap(lo, lo, false, false)
+                                : __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const uint2v h = DIST == 32 ? __builtin_amdgcn_permlane32_swap(hi, hi, false, false)
+                                : __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return op(__hiloint2double((int)h.x, (int)l.x), __hiloint2double((int)h.y, (int)l.y));
+}
+template <class Op>
+__device__ __forceinline__ double wave_allreduce(double v, Op op) {
+    v = op(v, dpp_move<0xB1>(v));                       // quad_perm [1,0,3,2]
+    v = op(v, dpp_move<0x4E>(v));                       // quad_perm [2,3,0,1]
+    v = op(v, dpp_move<0x141>(v));                      // row_half_mirror: the other quad of the 8-lane group
+    v = op(v, dpp_move<0x128>(v));                      // row_ror:8: the other half of the row
+    v = rows_combine<16>(v, op);
+    return rows_combine<32>(v, op);
+}
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-    return v;
+    return wave_allreduce(v, [](double a, double b) { return fmax(a, b); });
+}
+__device__ __forceinline__ double wave_sum(double v) {
+    return wave_allreduce(v, [](double a, double b) { return a + b; });
 }
 
 // psychoac.py:8-12

@@ -146,7 +146,6 @@ __device__ __forceinline__ void dd_add(double* hi, double* lo, double xh, double
 //                     register with the lower half (even rows) of another -- exactly one step of a transposing
 //                     butterfly: afterwards the lower lanes hold both halves' `a`, the upper lanes both halves' `b`;
 //   distance 8, 4, 2, 1: DPP row rotate / half mirror / quad permutes.
-typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
 template <int DIST>
 __device__ __forceinline__ double wave_xchg_add(double a, double b) {
     static_assert(DIST == 32 || DIST == 16, "swap distance");
@@ -158,13 +157,6 @@ __device__ __forceinline__ double wave_xchg_add(double a, double b) {
                                  : __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
     return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
 }
-template <int CTRL>
-__device__ __forceinline__ double dpp_move(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-
 // Sum each of 8 per-lane values over the 64 lanes of the wave and leave the 8 totals in every lane (wave-uniform).
 // Transposing butterfly: at distances 32, 16, 8 a lane hands HALF of its remaining values to its partner and adds
 // the partner's half of the others (4 + 2 + 1 exchanges instead of 8 x 6); three plain steps finish the one value
@@ -198,10 +190,7 @@ __device__ __forceinline__ void wave_sum_all(double* v, int lane) {
     for (int i = 0; i < n8; ++i) wave_sum_block<8>(v + 8 * i, lane);
 #pragma unroll
     for (int j = 8 * n8; j < N; ++j) {
-        double t = v[j];
-#pragma unroll
-        for (int offl = 32; offl > 0; offl >>= 1) t += __shfl_xor(t, offl);
-        v[j] = t;
+        v[j] = wave_sum(v[j]);
     }
 }
 
