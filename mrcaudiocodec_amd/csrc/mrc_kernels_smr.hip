@@ -256,12 +256,19 @@ __device__ __attribute__((noinline)) double excess_plain(double t, double a2, in
 // lines for the masker-side searches, the log10 table, the first quadrant of the FFT twiddles (-1: use global).
 struct SmrLds { int zbOff, logOff, twOff; };
 
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-        int o = __shfl_up(v, off);
-        if (lane >= off) v += o;
-    }
+// inclusive prefix sum over the 64 lanes, in registers: Kogge-Stone inside each 16-lane row with DPP row shifts (lanes
+// that would read across the row's start get 0), then the row totals are passed on with row_bcast:15 / row_bcast:31
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_shift_or_zero(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/) {
+    v += dpp_shift_or_zero<0x111, 0xf>(v);              // row_shr:1
+    v += dpp_shift_or_zero<0x112, 0xf>(v);              // row_shr:2
+    v += dpp_shift_or_zero<0x114, 0xf>(v);              // row_shr:4
+    v += dpp_shift_or_zero<0x118, 0xf>(v);              // row_shr:8
+    v += dpp_shift_or_zero<0x142, 0xa>(v);              // row_bcast:15 into rows 1 and 3
+    v += dpp_shift_or_zero<0x143, 0xc>(v);              // row_bcast:31 into rows 2 and 3
     return v;
 }
 
