@@ -262,6 +262,11 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_shift_or_zero(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_shift_or_zero(double v) {
+    return __hiloint2double(dpp_shift_or_zero<CTRL, ROW_MASK>(__double2hiint(v)),
+                            dpp_shift_or_zero<CTRL, ROW_MASK>(__double2loint(v)));
+}
 __device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/) {
     v += dpp_shift_or_zero<0x111, 0xf>(v);              // row_shr:1
     v += dpp_shift_or_zero<0x112, 0xf>(v);              // row_shr:2
@@ -580,21 +585,24 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
             constexpr int kSeg = 8;                     // kWave * kSeg = 512 >= max number of peaks (N/4)
             double loc[kSeg];
             double run = 0.0;
-#pragma unroll
+            const int seg = kWave - 1 - lane;           // lanes take the segments in REVERSE order, so that the suffix
+#pragma unroll                                          // over segments is a prefix over lanes (DPP shifts go up)
             for (int i = kSeg - 1; i >= 0; --i) {
-                const int m = lane * kSeg + i;
+                const int m = seg * kSeg + i;
                 run += (m < nPeaks) ? mt[4 * m + 3] : 0.0;
                 loc[i] = run;
             }
-            double higher = 0.0, carry = run;           // exclusive suffix scan of the segment totals
-#pragma unroll
-            for (int offl = 1; offl < kWave; offl <<= 1) {
-                double o = __shfl_down(carry, offl);
-                if (lane + offl < kWave) { carry += o; higher += o; }
-            }
+            double incl = run;                          // inclusive prefix over lanes of the segment totals
+            incl += dpp_shift_or_zero<0x111, 0xf>(incl);
+            incl += dpp_shift_or_zero<0x112, 0xf>(incl);
+            incl += dpp_shift_or_zero<0x114, 0xf>(incl);
+            incl += dpp_shift_or_zero<0x118, 0xf>(incl);
+            incl += dpp_shift_or_zero<0x142, 0xa>(incl);
+            incl += dpp_shift_or_zero<0x143, 0xc>(incl);
+            const double higher = dpp_shift_or_zero<0x138, 0xf>(incl);      // wave_shr:1 -> exclusive: the higher segments
 #pragma unroll
             for (int i = 0; i < kSeg; ++i) {
-                const int m = lane * kSeg + i;
+                const int m = seg * kSeg + i;
                 if (m < nPeaks) sc[m] = loc[i] + higher;
             }
             if (lane == 0) sc[nPeaks] = 0.0;
@@ -610,12 +618,13 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                 locH[i] = hi; locL[i] = lo;                            // exclusive within the segment
                 dd_add(&hi, &lo, (m < nPeaks) ? mt[4 * m] : 0.0, 0.0);
             }
-            double exH = 0.0, exL = 0.0, inH = hi, inL = lo;            // exclusive prefix scan of the segment totals
-#pragma unroll
-            for (int offl = 1; offl < kWave; offl <<= 1) {
-                const double oh = __shfl_up(inH, offl), ol = __shfl_up(inL, offl);
-                if (lane >= offl) { dd_add(&inH, &inL, oh, ol); dd_add(&exH, &exL, oh, ol); }
-            }
+            double inH = hi, inL = lo;                                  // inclusive prefix scan of the segment totals
+#define MRC_DD_SCAN_STEP(CTRL, MASK)                                                           \
+            dd_add(&inH, &inL, dpp_shift_or_zero<CTRL, MASK>(inH), dpp_shift_or_zero<CTRL, MASK>(inL));
+            MRC_DD_SCAN_STEP(0x111, 0xf) MRC_DD_SCAN_STEP(0x112, 0xf) MRC_DD_SCAN_STEP(0x114, 0xf)
+            MRC_DD_SCAN_STEP(0x118, 0xf) MRC_DD_SCAN_STEP(0x142, 0xa) MRC_DD_SCAN_STEP(0x143, 0xc)
+#undef MRC_DD_SCAN_STEP
+            const double exH = dpp_shift_or_zero<0x138, 0xf>(inH), exL = dpp_shift_or_zero<0x138, 0xf>(inL);   // exclusive
 #pragma unroll
             for (int i = 0; i < kSeg; ++i) {
                 const int m = lane * kSeg + i;
