@@ -45,7 +45,10 @@ __device__ __forceinline__ double order_value(unsigned long long k) {
 // far-field expansion (see the sweep): highest order, fewest maskers worth it, and for each supported order J the
 // largest |x| with |x|^(J+1)/(J+1)! e^|x| below 1e-17 (x = slope spread * half the Bark span of a group of lines)
 constexpr int kFarMaxOrder = 20;
-constexpr int kFarMinMaskers = 24;
+#ifndef MRC_FAR_MIN
+#define MRC_FAR_MIN 24
+#endif
+constexpr int kFarMinMaskers = MRC_FAR_MIN;
 constexpr double kFarLimit8 = 0.052, kFarLimit12 = 0.27, kFarLimit16 = 0.68, kFarLimit20 = 1.0;
 #ifndef MRC_FAR_MAX_ORDER                        // 20 costs 48 accumulator registers: spills around every chunk
 #define MRC_FAR_MAX_ORDER 16
