@@ -135,22 +135,6 @@ template <> __device__ __forceinline__ void butterfly<4>(double2* u) {
     u[3] = make_double2(b.x - d.y, b.y + d.x);
 }
 
-// radix 8: two radix-4 DFTs of the even / odd inputs after the odd ones are turned by W8^r (natural order out)
-template <> __device__ __forceinline__ void butterfly<8>(double2* u) {
-    const double h = 0.70710678118654752440;
-    double2 e[4] = {make_double2(u[0].x + u[4].x, u[0].y + u[4].y), make_double2(u[1].x + u[5].x, u[1].y + u[5].y),
-                    make_double2(u[2].x + u[6].x, u[2].y + u[6].y), make_double2(u[3].x + u[7].x, u[3].y + u[7].y)};
-    double2 o[4] = {make_double2(u[0].x - u[4].x, u[0].y - u[4].y), make_double2(u[1].x - u[5].x, u[1].y - u[5].y),
-                    make_double2(u[2].x - u[6].x, u[2].y - u[6].y), make_double2(u[3].x - u[7].x, u[3].y - u[7].y)};
-    o[1] = make_double2(h * (o[1].x + o[1].y), h * (o[1].y - o[1].x));       // * (1 - i)/sqrt2
-    o[2] = make_double2(o[2].y, -o[2].x);                                    // * (-i)
-    o[3] = make_double2(h * (o[3].y - o[3].x), -h * (o[3].x + o[3].y));      // * (-1 - i)/sqrt2
-    butterfly<4>(e);
-    butterfly<4>(o);
-    u[0] = e[0]; u[2] = e[1]; u[4] = e[2]; u[6] = e[3];
-    u[1] = o[0]; u[3] = o[1]; u[5] = o[2]; u[7] = o[3];
-}
-
 // Twiddle source of the block FFT.  TwGlobal: the full table exp(-2 pi i t/n) in global memory (any n).
 // TwQuarter: its first quadrant staged in LDS, n a power of two: w(s + q n/4) = w(s) (-i)^q -- same values, but no
 // global-load latency inside the passes (the FFT of a block is a chain of dependent, barrier-separated passes).
@@ -207,10 +191,8 @@ __device__ __forceinline__ double2* fft_lds(double2* A, double2* B, int n, const
     for (int s = 0; s < nrad; ++s) {
         const int R = rad[s];
         const bool pow2 = (p & (p - 1)) == 0;
-        if (R == 8 && pow2) fft_pass<8, true>(A, B, n, p, W, tid);
-        else if (R == 4 && pow2) fft_pass<4, true>(A, B, n, p, W, tid);
+        if (R == 4 && pow2) fft_pass<4, true>(A, B, n, p, W, tid);
         else if (R == 2 && pow2) fft_pass<2, true>(A, B, n, p, W, tid);
-        else if (R == 8) fft_pass<8, false>(A, B, n, p, W, tid);
         else if (R == 4) fft_pass<4, false>(A, B, n, p, W, tid);
         else if (R == 2) fft_pass<2, false>(A, B, n, p, W, tid);
         else if (pow2) fft_pass<3, true>(A, B, n, p, W, tid);
@@ -221,14 +203,13 @@ __device__ __forceinline__ double2* fft_lds(double2* A, double2* B, int n, const
     }
     return A;
 }
-// n a power of two (radix 8 / 4 / 2 passes only), twiddles from the LDS quadrant
+// n a power of two (radix 4 / 2 passes only), twiddles from the LDS quadrant
 __device__ __forceinline__ double2* fft_lds_pow2(double2* A, double2* B, int n, const int* rad, int nrad,
                                                  const TwQuarter& W, int tid) {
     int p = 1;
     for (int s = 0; s < nrad; ++s) {
         const int R = rad[s];
-        if (R == 8) fft_pass<8, true>(A, B, n, p, W, tid);
-        else if (R == 4) fft_pass<4, true>(A, B, n, p, W, tid);
+        if (R == 4) fft_pass<4, true>(A, B, n, p, W, tid);
         else fft_pass<2, true>(A, B, n, p, W, tid);
         __syncthreads();
         double2* t = A; A = B; B = t;

@@ -67,9 +67,6 @@ double bark(double f) {                               // psychoac.py:27-29
 
 bool factor(int n, int* rad, int* nrad) {
     int c = 0;
-    // two radix-8 passes where the length allows (fewer barrier-separated passes; a radix-8 pass keeps half of the
-    // 256 threads busy, so more than two do not pay), then 4s, 2s, 3s
-    for (int k = 0; k < 2 && n % 8 == 0 && n >= 64 && c < kMaxRadices; ++k) { rad[c++] = 8; n /= 8; }
     while (n % 4 == 0 && c < kMaxRadices) { rad[c++] = 4; n /= 4; }
     while (n % 2 == 0 && c < kMaxRadices) { rad[c++] = 2; n /= 2; }
     while (n % 3 == 0 && c < kMaxRadices) { rad[c++] = 3; n /= 3; }
