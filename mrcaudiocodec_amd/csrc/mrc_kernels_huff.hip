@@ -23,10 +23,16 @@ __constant__ unsigned char kCodeLen[4][kLutSize] = {
      0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 8}};
 __constant__ int kEscape[4] = {16, 11, 7, 7};
 
+// sum over the 64 lanes, in registers (DPP inside a 16-lane row, gfx950 permlane swaps across rows); all lanes active
 __device__ __forceinline__ int wave_sum_int(int v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);     // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);     // row_ror:8
+    const uint2v r16 = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = (int)(r16.x + r16.y);
+    const uint2v r32 = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)(r32.x + r32.y);
 }
 
 // grid: nFrames blocks of nStreams waves.  reservoirNext (may be null): reservoirOut[f] + sum over the frame's

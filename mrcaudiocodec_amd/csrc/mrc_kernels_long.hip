@@ -73,10 +73,26 @@ __device__ __forceinline__ void dft8(double2* u) {
     dft4(b0, b1, b2, b3, &u[1], &u[3], &u[5], &u[7]);
 }
 
+// max over the 64 lanes, in registers (DPP inside a 16-lane row, gfx950 permlane swaps across rows; same scheme as
+// dev::wave_allreduce in mrc_device.hpp, which this self-contained file does not include); all lanes active
+template <int CTRL> __device__ __forceinline__ double dpp_move(double v) {
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false));
+}
+typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-    return v;
+    v = fmax(v, dpp_move<0xB1>(v));
+    v = fmax(v, dpp_move<0x4E>(v));
+    v = fmax(v, dpp_move<0x141>(v));
+    v = fmax(v, dpp_move<0x128>(v));
+    {
+        const uint2v l = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+        const uint2v h = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+        v = fmax(__hiloint2double((int)h.x, (int)l.x), __hiloint2double((int)h.y, (int)l.y));
+    }
+    const uint2v l = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(v), (unsigned)__double2loint(v), false, false);
+    const uint2v h = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(v), (unsigned)__double2hiint(v), false, false);
+    return fmax(__hiloint2double((int)h.x, (int)l.x), __hiloint2double((int)h.y, (int)l.y));
 }
 
 __device__ __forceinline__ int scale_factor20(double v, int nScaleBits) {        // quantize.py:114-146, nMantBits = 5
