@@ -62,3 +62,26 @@ def c4_transients(n_hops, seed=42, floor=0.01, burst=0.5, period=5, short=128):
         else:
             shapes.append((off, a, HOP)); off += a; a = HOP
     return x, shapes
+
+
+def c6_varied(n_frames, seed=6):
+    """Mono material with a wide spread of masker levels and slopes inside every frame (what the far-field expansion
+    of smr_kernel keys its order on): noise whose level wanders over 60 dB from hop to hop, a few tones of very
+    different loudness that come and go, stretches of digital silence and full-scale clipping; 16-bit grid, the
+    usual leading hop of zeros.  Not a BASELINE config: a robustness corpus for parity sweeps and tests."""
+    rng = np.random.default_rng(seed)
+    n = (n_frames + 1) * 1024
+    t = np.arange(n)
+    level = 10.0 ** (rng.uniform(-4.0, -0.5, n_frames + 1))             # per-hop noise sigma, -80 .. -10 dBFS
+    x = rng.normal(0.0, 1.0, n) * np.repeat(level, 1024)
+    for _ in range(6):
+        f0 = rng.uniform(80.0, 16000.0)
+        amp = 10.0 ** rng.uniform(-3.5, -0.3)
+        gate = np.repeat(rng.random(n_frames + 1) < 0.6, 1024)
+        x += amp * np.sin(2 * np.pi * f0 * t / 48000.0 + rng.uniform(0, 6.28)) * gate
+    x[np.repeat(rng.random(n_frames + 1) < 0.05, 1024)] = 0.0            # silence
+    loud = np.repeat(rng.random(n_frames + 1) < 0.05, 1024)
+    x[loud] *= 30.0                                                      # clips
+    x = pcm_to_float(np.clip(np.rint(x * 32767.0), -32767, 32767))
+    x[:1024] = 0.0
+    return x

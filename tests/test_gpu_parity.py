@@ -162,6 +162,20 @@ def test_spread_modes_agree(h):
     _assert_int_parity(fast_out, exact_out)
     _assert_int_parity(exact_out, fast.encode_mono_batch(blocks, 1024, 1024))
     assert np.abs(thr_fast - thr_exact).max() <= 1e-10
+    # a corpus whose frames mix very loud and very quiet maskers: wide slope ranges send the far field through its
+    # higher orders, the two-group split and the direct fallback; silence and clipping exercise the SPL floor path
+    varied = np.array(fast.blocks_from_stream(synth.c6_varied(96, seed=11), 1024))
+    thr_fast = h.smr(varied, 1024, 1024, want_thresh=True)[1]
+    fast_out = h.encode_mono(varied, 1024, 1024)
+    h.set_option(1, 1)
+    try:
+        thr_exact = h.smr(varied, 1024, 1024, want_thresh=True)[1]
+        exact_out = h.encode_mono(varied, 1024, 1024)
+    finally:
+        h.set_option(1, 0)
+    _assert_int_parity(fast_out, exact_out)
+    _assert_int_parity(fast_out, fast.encode_mono_batch(varied, 1024, 1024))
+    assert np.abs(thr_fast - thr_exact).max() <= 1e-10
 
 
 @pytest.mark.parametrize("ab", SHAPES[1:])

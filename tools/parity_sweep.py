@@ -35,26 +35,7 @@ def compare(got, ref, keys, base):
 
 
 def varied_stream(n_frames, seed):
-    """Mono test material with a wide spread of masker levels and slopes inside every frame (what the far-field
-    expansion of smr_kernel keys its order on): noise whose level wanders over 60 dB from hop to hop, a few tones
-    of very different loudness that come and go, stretches of digital silence and full-scale clipping; 16-bit grid."""
-    rng = np.random.default_rng(seed)
-    n = (n_frames + 1) * 1024
-    t = np.arange(n)
-    level = 10.0 ** (rng.uniform(-4.0, -0.5, n_frames + 1))             # per-hop noise sigma, -80 .. -10 dBFS
-    x = rng.normal(0.0, 1.0, n) * np.repeat(level, 1024)
-    for _ in range(6):
-        f0 = rng.uniform(80.0, 16000.0)
-        amp = 10.0 ** rng.uniform(-3.5, -0.3)
-        gate = np.repeat(rng.random(n_frames + 1) < 0.6, 1024)
-        x += amp * np.sin(2 * np.pi * f0 * t / 48000.0 + rng.uniform(0, 6.28)) * gate
-    x[np.repeat(rng.random(n_frames + 1) < 0.05, 1024)] = 0.0            # silence
-    loud = np.repeat(rng.random(n_frames + 1) < 0.05, 1024)
-    x[loud] *= 30.0                                                      # clips
-    pcm = np.clip(np.rint(x * 32767.0), -32767, 32767)
-    x = np.sign(pcm) * 2.0 * np.abs(pcm) / 65535.0
-    x[:1024] = 0.0
-    return x
+    return synth.c6_varied(n_frames, seed)
 
 
 def main():
