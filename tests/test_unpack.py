@@ -68,3 +68,47 @@ def test_unpack_rejects_damaged_input():
     bad[chunks[0] + 4] = 0x4F                                # table id 4: not a table, not raw
     with pytest.raises(ppac.MrcError):
         ppac.unpack_blocks(cfg, bytes(bad), chunks[:2], 2, True)
+
+
+@pytest.mark.parametrize("shape", [(1024, 1024), (128, 128), (1024, 128), (128, 1024)])
+@pytest.mark.parametrize("huff", [False, True])
+def test_pack_unpack_round_trip_random_blocks(shape, huff):
+    # packer -> parser on random contents of every block shape: allocations 0 / 2..16, mantissas covering every
+    # table entry, the escape values and beyond; joint and independent channels
+    a, b = shape
+    cfg = ppac.make_config()
+    bands = ppac.band_table(cfg, a, b)
+    nb, half, n = len(bands), (a + b) // 2, 24
+    rng = np.random.default_rng(a + 7 * b + int(huff))
+    line_band = np.repeat(np.arange(nb), bands)
+    ba = rng.integers(0, 17, size=(n, 2, nb)).astype(np.int32)
+    ba[ba == 1] = 0
+    ba[:3] = 0                                               # blocks without any mantissa
+    scale = np.array([1, 2, 3, 5, 9, 17, 33, 65, 70, 1 << 16])[rng.integers(0, 10, size=(n, 2, 1))]
+    mant = (rng.integers(0, 1 << 16, size=(n, 2, half)) % scale).astype(np.int64)
+    mant = np.minimum(mant, (1 << np.maximum(ba[:, :, line_band], 1)) - 1).astype(np.int32)
+    mant[ba[:, :, line_band] == 0] = 0
+    sf = rng.integers(0, 16, size=(n, 2, nb)).astype(np.int32)
+    osc4 = rng.integers(0, 16, size=(n, 4)).astype(np.int32)
+    sw = rng.integers(0, 2, size=(n, nb)).astype(np.int32)
+    head = ppac.header(cfg, 2, n * b)
+
+    data, offs, table, _ = ppac.pack_joint_blocks(cfg, a, b, osc4, sw, sf, ba, mant, huff)
+    blob = head + data.tobytes()
+    chunks = ppac.scan_chunks(blob, len(head))
+    assert len(chunks) == 2 * n
+    got = ppac.unpack_blocks(cfg, blob, chunks, 2, True)
+    assert (got["a"] == a).all() and (got["b"] == b).all()
+    assert np.array_equal(got["huff_table"], table)
+    assert np.array_equal(got["overall_scale"], osc4) and np.array_equal(got["ms_switch"][:, :nb], sw)
+    assert np.array_equal(got["scale_factor"][:, :, :nb], sf) and np.array_equal(got["bit_alloc"][:, :, :nb], ba)
+    assert np.array_equal(got["mantissa"][:, :, :half], mant) and not got["mantissa"][:, :, half:].any()
+
+    data, offs, table, _ = ppac.pack_blocks(cfg, a, b, osc4[:, :2], sf, ba, mant, huff)
+    blob = head + data.tobytes()
+    got = ppac.unpack_blocks(cfg, blob, ppac.scan_chunks(blob, len(head)), 2, False)
+    assert np.array_equal(got["huff_table"], table) and np.array_equal(got["overall_scale"], osc4[:, :2])
+    assert np.array_equal(got["scale_factor"][:, :, :nb], sf) and np.array_equal(got["bit_alloc"][:, :, :nb], ba)
+    assert np.array_equal(got["mantissa"][:, :, :half], mant)
+    if huff:
+        assert (table != 15).any()
