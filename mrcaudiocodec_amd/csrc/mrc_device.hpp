@@ -41,8 +41,9 @@ __device__ __forceinline__ unsigned xcd_contiguous(unsigned b, unsigned g) {
 typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    // every lane has a valid source for the controls used here, so no "old" value has to be prepared
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 template <int DIST, class Op>

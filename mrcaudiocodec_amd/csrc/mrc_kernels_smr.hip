@@ -220,10 +220,14 @@ __device__ __forceinline__ double far_group(const double* __restrict__ mt, int n
             term *= da;
         }
     }
-    wave_sum_all<NB>(B, lane);
-    double p = B[J] * kInvFactorial[J];
+    // 1/j! goes onto the per-lane partial sums: the wave totals come back as scalars, and a scalar times a constant
+    // would need a register copy first
 #pragma unroll
-    for (int j = J - 1; j >= 0; --j) p = fma(p, d, B[j] * kInvFactorial[j]);
+    for (int j = 2; j <= J; ++j) B[j] *= kInvFactorial[j];
+    wave_sum_all<NB>(B, lane);
+    double p = B[J];
+#pragma unroll
+    for (int j = J - 1; j >= 0; --j) p = fma(p, d, B[j]);
     return p * exp2_tab64(slMid, d, e2tab);
 }
 
@@ -263,6 +267,9 @@ struct SmrLds { int zbOff, logOff, twOff; };
 // that would read across the row's start get 0), then the row totals are passed on with row_bcast:15 / row_bcast:31
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_shift_or_zero(int v) {
+    // all rows enabled: bound_ctrl supplies the zero of lanes without a source; a partial row mask leaves the other
+    // rows' lanes to the prepared zero
+    if (ROW_MASK == 0xf) return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true);
     return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
 }
 template <int CTRL, int ROW_MASK>
