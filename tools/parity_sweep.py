@@ -43,10 +43,38 @@ def main():
     ap.add_argument("--mono", type=int, default=16384)
     ap.add_argument("--joint", type=int, default=4096)
     ap.add_argument("--varied", type=int, default=0, help="frames of the varied-level corpus (mono and as L/R pair)")
+    ap.add_argument("--shapes", type=int, default=0, help="blocks per short / transition shape (mono, and a quarter joint)")
     ap.add_argument("--chunk", type=int, default=1024)
     args = ap.parse_args()
     h = Handle()
     t0 = time.time()
+    for (a, b) in ((128, 128), (1024, 128), (128, 1024)) if args.shapes else ():
+        for joint, n in ((False, args.shapes), (True, args.shapes // 4)):
+            frames_bad, entries_bad, mdct_err = set(), 0, 0.0
+            rng = np.random.default_rng(a * 31 + b + int(joint))
+            for base in range(0, n, args.chunk * 4):
+                c = min(args.chunk * 4, n - base)
+                sig = 10.0 ** rng.uniform(-3.0, -0.3, (c, 1))          # per-block level, -60 .. -6 dBFS
+                mk = lambda: synth.pcm_to_float(np.clip(np.rint(rng.normal(0, 1, (c, a + b)) * sig * 32767), -32767, 32767))
+                bl = mk()
+                res_in = rng.integers(-100, 200, c)
+                if joint:
+                    br = np.where((np.arange(c) % 2 == 0)[:, None], 0.9 * bl + 0.1 * mk(), mk())
+                    got = h.encode_joint(bl, br, a, b, res_in, want_mdct=True)
+                    ref = fast.encode_joint_batch(bl, br, a, b, res_in)
+                    keys = INT_KEYS + ("ms_switch",)
+                else:
+                    got = h.encode_mono(bl, a, b, res_in, want_mdct=True)
+                    ref = fast.encode_mono_batch(bl, a, b, res_in)
+                    keys = INT_KEYS
+                fb, eb = compare(got, ref, keys, base)
+                frames_bad |= fb
+                entries_bad += eb
+                mdct_err = max(mdct_err, float(np.abs(got["mdct"] - ref["mdct"]).max() / max(np.abs(ref["mdct"]).max(), 1e-300)))
+                print("shape %dx%d %s: %d/%d blocks done, %d mismatching so far (%.0f s)" %
+                      (a, b, "joint" if joint else "mono", base + c, n, len(frames_bad), time.time() - t0), flush=True)
+            print("RESULT shape %dx%d %s noise of varying level: blocks=%d mismatching_blocks=%d mismatching_entries=%d max_rel_mdct_err=%.3g" %
+                  (a, b, "joint" if joint else "mono", n, len(frames_bad), entries_bad, mdct_err), flush=True)
     for name, n, joint in (("mono varied levels/tones/silence/clipping", args.varied, False),
                            ("joint varied levels/tones/silence/clipping", args.varied // 4, True)):
         frames_bad, entries_bad, mdct_err = set(), 0, 0.0
