@@ -10,8 +10,11 @@ HOP = 1024
 
 
 def pcm_to_float(pcm):
+    """int16 code c -> sign(c) * 2|c| / 65535; -32768 -> 0.0 (its magnitude 2^15 is read as a bare sign bit:
+    pcmfile.py:91-100 + quantize.py:90-111; pinned by tests/golden/ref_encode.npz `pcmmap_*`)."""
     p = np.asarray(pcm, dtype=np.float64)
-    return np.sign(p) * 2.0 * np.abs(p) / 65535
+    mag = np.abs(p)
+    return np.where(mag >= 32768, 0.0, np.sign(p) * 2.0 * mag / 65535)
 
 
 def _gauss_pcm(seed, n, sigma):

@@ -1,0 +1,194 @@
+"""
+CPU tests: the oracle (and the host-only parts of the product) against outputs of the reference's OWN functions
+(tests/golden/ref_*.npz, recorded by tests/golden/make_golden_ref.py through the Python-2-semantics harness
+tests/golden/py2harness.py).  These fixtures are what pins SURVEY 8(a) rows a1/a2 (KBD / transition window),
+a3 (MDCT), a7/a8 (getMaskedThreshold / CalcSMRs), a9 (band tables), a15-a17 (orchestration, budgets, reservoir,
+Huffman gain) and the decoder core (Decode / JointDecode) -- bit-exact for every integer; float outputs are compared
+bit-exactly too where the oracle performs the same NumPy operations in the same order (it does), with a 1-ulp
+allowance only where stated.
+"""
+import numpy as np
+import pytest
+
+import refgold as G
+from oracle import codec as ocodec, decode as odec, fast, mdct as omdct, psychoac as opsy, window as owin
+
+
+def _ulp_close(a, b, ulps=1):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return np.all(np.abs(a - b) <= ulps * np.spacing(np.maximum(np.abs(a), np.abs(b))))
+
+
+# ------------------------------------------------------------------------------------------------ psychoac.py:8-131
+def test_pcm_map_matches_reference():
+    e = G.load("ref_encode.npz")
+    assert np.array_equal(G.pcm_to_float(e["pcmmap_in"]), e["pcmmap_out"])
+    from mrcaudiocodec_amd import synth
+    assert np.array_equal(synth.pcm_to_float(e["pcmmap_in"]), e["pcmmap_out"])
+
+
+def test_psychoac_primitives_match_reference():
+    p = G.load("ref_psychoac.npz")
+    with np.errstate(divide="ignore"):
+        assert np.array_equal(opsy.SPL(p["spl_in"]), p["spl_out"])
+    assert np.array_equal(opsy.Intensity(p["int_in"]), p["int_out"])
+    assert np.array_equal(opsy.Bark(p["f_in"]), p["bark_out"])
+    assert np.array_equal(opsy.Thresh(p["f_in"]), p["thresh_out"])
+    for half, fs in p["grids"]:
+        key = "%d_%d" % (half, fs)
+        f = (np.arange(half) + 0.5) * ((float(fs) / half) / 2.)
+        assert np.array_equal(f, p["freq_" + key])
+        assert np.array_equal(opsy.Thresh(f), p["thresh_" + key])
+        assert np.array_equal(opsy.Bark(f), p["bark_" + key])
+        assert np.array_equal(opsy.Intensity(opsy.Thresh(f)), p["quiet_" + key])
+        assert np.array_equal(opsy.SPL(opsy.Intensity(opsy.Thresh(f))), p["spl_quiet_" + key])
+
+
+def test_masker_spreading_matches_reference():
+    p = G.load("ref_psychoac.npz")
+    for f, spl, out, ze, oute in zip(p["mk_f"], p["mk_spl"], p["mk_out"], p["mk_edge_z"], p["mk_edge_out"]):
+        m = opsy.Masker(float(f), float(spl))
+        assert np.array_equal(m.vIntensityAtBark(p["mk_zgrid"]), out), (f, spl)
+        assert np.array_equal(m.vIntensityAtBark(ze), oute), (f, spl)      # |dz| == 0.5 exactly included
+
+
+def test_band_tables_match_reference():
+    p = G.load("ref_psychoac.npz")
+    n = 0
+    for key in p.files:
+        if not key.startswith("bt_assign_"):
+            continue
+        half, fs, kind = key[len("bt_assign_"):].split("_")
+        lim = None if kind == "cb" else G.SHORT_LIMITS
+        nl = opsy.AssignMDCTLinesFromFreqLimits(int(half), int(fs)) if lim is None else \
+            opsy.AssignMDCTLinesFromFreqLimits(int(half), int(fs), lim)
+        assert np.array_equal(np.asarray(nl, dtype=np.float64), p[key]), key
+        sfb = opsy.ScaleFactorBands(nl)
+        tail = key[len("bt_assign_"):]
+        assert np.array_equal(sfb.lowerLine, p["bt_lower_" + tail])
+        assert np.array_equal(sfb.upperLine, p["bt_upper_" + tail])
+        assert np.array_equal(sfb.nLines, p["bt_nlines_" + tail])
+        n += 1
+    assert n == 15
+
+
+def test_product_band_table_matches_reference():
+    """mrc_band_table (host only, no device handle) against the reference's AssignMDCTLinesFromFreqLimits at the
+    block shapes the encoder uses (pacfileThem.py:637-645)."""
+    from mrcaudiocodec_amd import pacfile
+    p = G.load("ref_psychoac.npz")
+    for fs in (48000, 44100, 32000):
+        cfg = pacfile.make_config(sample_rate=fs)
+        for (a, b), key in (((1024, 1024), "1024_%d_cb"), ((1024, 128), "576_%d_short"), ((128, 1024), "576_%d_short"),
+                            ((128, 128), "128_%d_short")):
+            got = pacfile.band_table(cfg, a, b)
+            assert np.array_equal(np.asarray(got, dtype=np.int64), p["bt_nlines_" + key % fs]), (fs, a, b)
+
+
+def test_calcsmr_arithmetic_matches_reference():
+    """psychoac.py:212-217 with a given threshold: SPL of the scaled lines minus 6 dB per scale step, band maxima."""
+    p = G.load("ref_psychoac.npz")
+    sfb = G.bands(1024, 1024, 48000)
+    lines, thr = p["smrpost_lines"], p["smrpost_thr"]
+    for sc, want in zip(p["smrpost_scales"], p["smrpost_out"]):
+        with np.errstate(divide="ignore"):
+            spl = opsy.SPL(2. * (np.abs(lines) ** 2.) / (1. / 2.)) - 6. * sc
+        got = np.array([np.amax((spl - thr)[sfb.lowerLine[i]:sfb.upperLine[i] + 1]) for i in range(sfb.nBands)])
+        assert np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------ window.py:49-121
+def test_kbd_and_transition_window_match_reference():
+    w = G.load("ref_window.npz")
+    for N in (2048, 256, 16):
+        assert np.array_equal(owin.KBDWindow(np.ones(N)), w["kbd_%d" % N]), N
+    for (a, b) in G.SHAPES + [(8, 4)]:
+        assert np.array_equal(owin.TransitionWindow(np.ones(a + b), a, b), w["trans_%d_%d" % (a, b)]), (a, b)
+        assert np.array_equal(owin.TransitionWindow(w["x_%d_%d" % (a, b)], a, b), w["xwin_%d_%d" % (a, b)]), (a, b)
+        if a >= 128:
+            assert np.array_equal(fast.transition_table(a, b), w["trans_%d_%d" % (a, b)]), (a, b)
+
+
+# ------------------------------------------------------------------------------------------------ mdct.py:53-122
+def test_mdct_imdct_match_reference():
+    m = G.load("ref_mdct.npz")
+    for (a, b) in G.SHAPES + [(8, 4), (4, 4)]:
+        key = "%d_%d" % (a, b)
+        x, X = m["x_" + key], m["X_" + key]
+        got = np.array([omdct.MDCT(r, a, b) for r in x])
+        assert np.array_equal(got, m["mdct_" + key]), key
+        if m["slow_" + key].size:
+            slow = np.array([omdct.MDCTslow(r, a, b) for r in x])
+            assert np.array_equal(slow, m["slow_" + key]), key
+        inv = np.array([odec.IMDCT(r, a, b) for r in X])
+        assert np.array_equal(inv, m["imdct_" + key]), key
+        if a >= 128:       # the batched oracle windows the block itself: compare with MDCT(TransitionWindow(x))
+            want = np.array([omdct.MDCT(owin.TransitionWindow(r, a, b), a, b) for r in x])
+            assert np.abs(fast.mdct_batch(x, a, b) - want).max() <= 1e-12 * np.abs(want).max()
+
+
+# ------------------------------------------------------------------------------------------------ psychoac.py:134-219
+@pytest.mark.parametrize("fs", [48000, 44100])
+def test_masked_threshold_and_smr_match_reference(fs):
+    s = G.load("ref_smr.npz")
+    for (a, b) in G.SHAPES:
+        key = "%d_%d_%d" % (a, b, fs)
+        sfb = G.bands(a, b, fs)
+        N = a + b
+        blocks = np.array([G.pcm_to_float(r) for r in s["pcm_" + key]])
+        for i, x in enumerate(blocks):
+            X = omdct.MDCT(owin.TransitionWindow(x, a, b), a, b)[:N // 2]
+            sc = int(s["scale_" + key][i])
+            X = X * (1 << sc)
+            thr = opsy.getMaskedThreshold(x, X, sc, fs, sfb)
+            assert np.array_equal(thr, s["thr_" + key][i]), (key, i)
+            assert np.array_equal(opsy.CalcSMRs(x, X, sc, fs, sfb), s["smr_" + key][i]), (key, i)
+        # the vectorised oracle (what the GPU parity tests at scale compare with) on the same blocks
+        thr_fast = fast.masked_threshold_batch(blocks, N // 2, fs)
+        assert np.abs(thr_fast - s["thr_" + key]).max() <= 1e-9, key
+
+
+# ------------------------------------------------------------------------------------------------ codecThem.py
+@pytest.mark.parametrize("tag,kind", [("single", "single"), ("nohuff", "nohuff"), ("jointch", "jointch"),
+                                      ("joint", "joint"), ("indep", "indep"), ("jointlo", "joint"),
+                                      ("jointtrain", "joint")])
+def test_encode_chains_match_reference(tag, kind):
+    e = G.load("ref_encode.npz")
+    assert list(e["table_order"]) == list(ocodec.TABLE_ORDER)
+    G.check_chain(ocodec, e, tag, kind)
+
+
+def test_fast_oracle_matches_reference_chain():
+    """oracle.fast (batched, used by the large GPU parity tests) on the recorded blocks, reservoirs given."""
+    e = G.load("ref_encode.npz")
+    for tag, joint in (("single", False), ("jointch", True)):
+        blocks = G.blocks_of(e, tag)
+        for i, (a, b, full) in enumerate(blocks):
+            k = "%s_%d" % (tag, i)
+            res_in = np.array([int(e[tag + "_res_in"][i])])
+            if joint:
+                r = fast.encode_joint_batch(full[0][None], full[1][None], a, b, reservoir_in=res_in)
+                assert np.array_equal(r["ms_switch"][0], e[k + "_ms"])
+                assert np.array_equal(r["mantissa"][0, 0], e[k + "_mant0"]) and np.array_equal(r["mantissa"][0, 1], e[k + "_mant1"])
+                assert np.array_equal(r["bit_alloc"][0], e[k + "_ba"]) and np.array_equal(r["scale_factor"][0], e[k + "_sf"])
+                assert np.array_equal(r["overall_scale"][0], e[k + "_os"])
+            else:
+                r = fast.encode_mono_batch(full[0][None], a, b, reservoir_in=res_in)
+                assert np.array_equal(r["mantissa"][0], e[k + "_mant0"])
+                assert np.array_equal(r["bit_alloc"][0], e[k + "_ba"][0]) and np.array_equal(r["scale_factor"][0], e[k + "_sf"][0])
+                assert int(r["overall_scale"][0]) == int(e[k + "_os"][0])
+            assert int(r["reservoir_out"][0]) == int(e[tag + "_res_out"][i]), (tag, i)
+
+
+def test_decoders_match_reference():
+    e = G.load("ref_encode.npz")
+    cp = G.params_from(e, "jointch")
+    for i in range(int(e["dec_n"])):
+        k = "dec_%d" % i
+        a, b = (int(v) for v in e[k + "_shape"])
+        cp.a, cp.b, cp.sfBands = a, b, G.bands(a, b, 48000)
+        out = odec.JointDecode(list(e[k + "_sf"]), list(e[k + "_ba"]), [e[k + "_mant0"], e[k + "_mant1"]],
+                               list(e[k + "_os"]), cp, list(e[k + "_ms"]))
+        assert np.array_equal(np.array(out), e[k + "_jointdec"]), k
+        one = odec.Decode(e[k + "_sf1"], e[k + "_ba1"], e[k + "_mant1ch"], int(e[k + "_os1"]), cp)
+        assert np.array_equal(one, e[k + "_dec"]), k
