@@ -102,3 +102,30 @@ def test_decode_matches_reference(handles):
         one = h.decode(a, b, np.array([int(e[k + "_os1"])]), e[k + "_sf1"][None, None], e[k + "_ba1"][None, None],
                        e[k + "_mant1ch"][None, None])[0, 0]
         assert np.abs(one - e[k + "_dec"]).max() <= 1e-12 * np.abs(e[k + "_dec"]).max(), k
+
+
+# ------------------------------------------------------------------------------------------------ file level
+# tests/golden/ref_pac.npz: what the reference's command-line driver wrote for synthetic WAV files
+# (tests/golden/make_golden_pac.py).  The product's CLI path -- WAV ingest, transient detector kernel, chained joint
+# blocks on the device, Huffman + bit packing in C++ -- must write the same bytes, and its decoder the same samples.
+@pytest.mark.parametrize("case", ["a48", "b44"])
+def test_cli_pac_bytes_equal_reference_cli(tmp_path, case):
+    from mrcaudiocodec_amd import cli
+    g = G.load("ref_pac.npz")
+    path = str(tmp_path / "in.wav")
+    with open(path, "wb") as f:
+        f.write(cli.wav_bytes(g[case + "_pcm"], int(g[case + "_rate"])))
+    assert cli.encode_wav(path, use_huffman=True) == g[case + "_pac"].tobytes()
+    assert cli.encode_wav(path, use_huffman=False) == g[case + "_pac_raw"].tobytes()
+
+
+@pytest.mark.parametrize("case", ["a48", "b44"])
+def test_cli_decode_equals_reference_cli(tmp_path, case):
+    from mrcaudiocodec_amd import cli
+    g = G.load("ref_pac.npz")
+    pac = str(tmp_path / "in.pac")
+    with open(pac, "wb") as f:
+        f.write(g[case + "_pac"].tobytes())
+    pcm = cli.decode_pac_file(pac, str(tmp_path / "out.wav"))
+    want = g[case + "_decoded"]             # its first 1024 samples are the reference driver's stale look-ahead block
+    assert np.array_equal(pcm[:, :want.shape[1] - 1024], want[:, 1024:])

@@ -192,3 +192,67 @@ def test_decoders_match_reference():
         assert np.array_equal(np.array(out), e[k + "_jointdec"]), k
         one = odec.Decode(e[k + "_sf1"], e[k + "_ba1"], e[k + "_mant1ch"], int(e[k + "_os1"]), cp)
         assert np.array_equal(one, e[k + "_dec"]), k
+
+
+# ------------------------------------------------------------------------------------------------ pacfileThem.py
+# tests/golden/ref_pac.npz: the reference's command-line driver executed as a script on synthetic WAV files
+# (tests/golden/make_golden_pac.py): its .pac bytes with and without Huffman tables and the WAV it decoded.
+def _wav_file(tmp_path, pcm, rate):
+    from mrcaudiocodec_amd import cli
+    path = str(tmp_path / "in.wav")
+    with open(path, "wb") as f:
+        f.write(cli.wav_bytes(pcm, rate))
+    return path
+
+
+@pytest.mark.parametrize("case", ["a48", "b44"])
+def test_oracle_pac_bytes_equal_reference_cli(tmp_path, case):
+    from oracle import pacfile as opac
+    g = G.load("ref_pac.npz")
+    path = _wav_file(tmp_path, g[case + "_pcm"], int(g[case + "_rate"]))
+    assert opac.encode_wav(path, huffman=True) == g[case + "_pac"].tobytes()
+    assert opac.encode_wav(path, huffman=False) == g[case + "_pac_raw"].tobytes()
+
+
+@pytest.mark.parametrize("case", ["a48", "b44"])
+def test_oracle_decode_equals_reference_cli(case):
+    g = G.load("ref_pac.npz")
+    want = g[case + "_decoded"]
+    cp, x = odec.decode_pac(g[case + "_pac"].tobytes())
+    got = odec.pcm16(x)
+    assert np.array_equal(got[:, 1024:want.shape[1]], want[:, 1024:])
+    # the reference's first written block is its encode direction's look-ahead buffer, i.e. the last input block
+    pcm = g[case + "_pcm"]
+    last = np.zeros((2, 1024), dtype=np.int16)
+    tail = pcm[:, (pcm.shape[1] - 1) // 1024 * 1024:]
+    last[:, :tail.shape[1]] = tail
+    last = np.where(last == -32768, 0, last)            # -32768 reads as 0.0 (pcmfile.py:91-100)
+    assert np.array_equal(want[:, :1024], last)
+
+
+@pytest.mark.parametrize("case", ["a48", "b44"])
+def test_host_parser_on_reference_written_file(case):
+    """mrc_pac_read_header / mrc_pac_scan_chunks / mrc_unpack_blocks (host C++, no GPU) on bytes the reference wrote."""
+    from mrcaudiocodec_amd import pacfile as ppac
+    g = G.load("ref_pac.npz")
+    pac = g[case + "_pac"].tobytes()
+    cfg, nch, num_samples, off = ppac.read_header(pac)
+    cp, off_ref = odec.read_header(pac)
+    n = g[case + "_pcm"].shape[1]
+    n_hdr = n + 1024 if n % 1024 == 0 else n           # the header's inverted padding test (pacfileThem.py:595-597)
+    assert (cfg.sample_rate, nch, num_samples, off) == (int(g[case + "_rate"]), 2, n_hdr, off_ref)
+    chunks = ppac.scan_chunks(pac, off)
+    ref_chunks = odec.split_chunks(pac, off_ref)
+    n_joint = len(chunks) // 2 - 1
+    got = ppac.unpack_blocks(cfg, pac, chunks[:2 * n_joint], 2, True)
+    assert (got["huff_table"] != 15).any() and (got["b"] == 128).any()
+    for i in range(n_joint):
+        want = odec.parse_joint_block(ref_chunks[2 * i], ref_chunks[2 * i + 1], cp)
+        nb, half = cp.sfBands.nBands, (cp.a + cp.b) // 2
+        assert (got["a"][i], got["b"][i]) == (cp.a, cp.b)
+        assert list(got["huff_table"][i]) == want["huffTable"] and list(got["overall_scale"][i]) == want["overallScale"]
+        assert list(got["ms_switch"][i, :nb]) == want["ms_switch"]
+        for ch in range(2):
+            assert list(got["scale_factor"][i, ch, :nb]) == want["scaleFactor"][ch]
+            assert list(got["bit_alloc"][i, ch, :nb]) == want["bitAlloc"][ch]
+            assert np.array_equal(got["mantissa"][i, ch, :half], want["mantissa"][ch][:half])
