@@ -4,8 +4,8 @@ oracle.codec -- per-block encode orchestration (TEST ORACLE, "faithful" flavour)
 Restates codecThem.py:281-354 (EncodeSingleChannel), 359-574 (JointEncodeChannels),
 205-231 (Encode), 234-260 (EncodeNoHuff), 262-278 (JointEncode), 136-203 (calculateHuffmanGain),
 audiofile.py:51-53 (CodingParams) and the block framing / band-table choice of
-pacfileThem.py:628-645, 799-816, 1105-1121.  The reference module is a py2 SyntaxError under
-Python 3 and no reference test covers it => PARITY UNPINNED (see oracle/__init__.py).
+pacfileThem.py:628-645, 799-816, 1105-1121.  Pinned by tests/golden/ref_encode.npz: the reference's own
+functions executed through tests/golden/py2harness.py (see oracle/__init__.py); bit-exact.
 
 One block at a time, with the reference's redundancy kept (window tables rebuilt per call, the
 masked threshold evaluated twice per CalcSMRs, two extra thresholds for the dead M/S masking

@@ -14,8 +14,10 @@ Restates, block by block like the reference:
 
 Pinned by golden vectors recorded from the reference's own py3-importable functions (vDequantize,
 vDequantizeUniform, ReconstructLR: tests/golden/decode.npz) and by the TDAC known-answer vector of mdct.py:131-182;
-IMDCT, Decode/JointDecode and the chunk parser are PARITY UNPINNED (not importable, no fixture), the restatement is
-the specification there.
+IMDCT / Decode / JointDecode by tests/golden/ref_mdct.npz and ref_encode.npz (the reference's functions executed through
+tests/golden/py2harness.py, bit-exact), and the chunk parser + overlap-and-add by ref_pac.npz: the WAV the
+reference's own driver decoded equals this decoder's 16-bit codes from the second block on (its first written block
+is a stale encode-direction buffer, see tests/golden/make_golden_pac.py).
 
 Two deliberate differences from the reference's file layer, both documented in DESIGN.md:
   * Huffman codes are decoded from the code TABLES (the same prefix code the pickled trees hold; the tree pickles

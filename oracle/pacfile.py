@@ -4,9 +4,10 @@ oracle.pacfile -- bit packing and `.pac` framing of encoded blocks (TEST ORACLE)
 Restates bitpack.py:13-101 (PackedBits.WriteBits, MSB first), pacfileThem.py:586-619 (file header),
 622-790 (WriteDataBlock: independent channels), 793-972 (JointWriteDataBlock), 973-984 (Close: one
 extra NON-joint block of zeros) and the driver loop of pacfileThem.py:1159-1214 for a given sequence
-of block shapes.  Pinned only by the reference's bit-packer known-answer vector
-(bitpack.py:183-196: (3,5,11,3,1) in (4,3,5,3,1) bits -> 0x3A 0xB7, tests/test_oracle.py); the chunk
-layouts themselves are PARITY UNPINNED (the committed .pac files come from an older encoder).
+of block shapes.  Pinned by tests/golden/ref_pac.npz -- the .pac files the reference's own driver
+(pacfileThem.py run as a script through tests/golden/py2harness.py) wrote for synthetic WAV files, with and
+without Huffman tables: encode_wav() reproduces them byte for byte (tests/test_reference_golden.py) -- and by the
+bit-packer known-answer vector (bitpack.py:183-196: (3,5,11,3,1) in (4,3,5,3,1) bits -> 0x3A 0xB7).
 Huffman table ids follow oracle.huffman_tables.TABLE_ORDER.
 """
 from struct import pack

@@ -3,9 +3,10 @@ oracle.psychoac -- psychoacoustic model: masked threshold and signal-to-mask rat
 
 Restates psychoac.py:8-29 (SPL, Intensity, Thresh, Bark), 31-78 (Masker), 82-105 (cbFreqLimits,
 AssignMDCTLinesFromFreqLimits), 107-131 (ScaleFactorBands), 134-173 (getMaskedThreshold),
-176-219 (CalcSMRs).  The reference module is not importable under Python 3 (it imports mdct.py,
-a py2 SyntaxError) and the reference holds no test or fixture for it => PARITY UNPINNED: this
-restatement is the specification.  Python-2 semantics that change results are marked `py2:`.
+176-219 (CalcSMRs).  Pinned by tests/golden/ref_psychoac.npz (primitives, maskers incl. |dz| == 0.5, band tables)
+and ref_smr.npz (getMaskedThreshold / CalcSMRs on every block shape at 48 and 44.1 kHz): outputs of the reference's
+own functions executed through tests/golden/py2harness.py -- equal bit for bit, floats included
+(tests/test_reference_golden.py).  Python-2 semantics that change results are marked `py2:`.
 """
 import numpy as np
 from .window import HanningWindow

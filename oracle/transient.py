@@ -3,8 +3,9 @@ oracle.transient -- transient detector and block-shape sequencing of the encoder
 
 Restates pacfileThem.py:1025-1056 (TransientDetector), 1146-1154 (filter design and thresholds) and the
 block-switching decisions of the driver loop, pacfileThem.py:1159-1214.  Uses SciPy for the filter design
-and the filtering exactly like the reference (signal.cheby2 / tf2sos / sosfilt).  PARITY UNPINNED: the
-reference holds no test or fixture for it; this restatement is the specification.
+and the filtering exactly like the reference (signal.cheby2 / tf2sos / sosfilt).  Pinned end to end by
+tests/golden/ref_pac.npz: the .pac files the reference's own driver wrote for WAV files with bursts contain its
+block-shape decisions, and the oracle's bytes equal them (tests/test_reference_golden.py).
 """
 import numpy as np
 from scipy import signal

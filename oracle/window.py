@@ -3,10 +3,11 @@ oracle.window -- analysis windows (TEST ORACLE).
 
 Restates window.py:28-45 (HanningWindow), 49-101 (KBDWindow, alpha=4), 104-121
 (TransitionWindow).  HanningWindow is pinned by tests/golden/window.npz (vectors produced by
-importing the reference's window.py).  KBDWindow / TransitionWindow cannot run under Python 3 /
-NumPy 2 in the reference (float `num` to np.linspace, window.py:60) => PARITY UNPINNED; they are
-held to the formula the reference cites (Bosi & Goldberg pp.108-109) and to the Princen-Bradley
-property win^2[n] + win^2[n+N/2] == 1 in tests/test_oracle.py.
+importing the reference's window.py).  KBDWindow / TransitionWindow raise under plain NumPy 2 in the
+reference (float `num` to np.linspace, window.py:60); they are pinned by tests/golden/ref_window.npz, produced by
+the reference's own functions executed through tests/golden/py2harness.py (float sizes taken as NumPy < 1.12
+did) -- bit-exact (tests/test_reference_golden.py) -- and additionally held to the Princen-Bradley property
+win^2[n] + win^2[n+N/2] == 1 in tests/test_oracle.py.
 """
 import numpy as np
 

@@ -112,7 +112,7 @@ def test_hann_golden(golden_dir):
         assert np.array_equal(window.HanningWindow(g["x_%d" % N]), g["hann_%d" % N])
 
 
-# ------------------------------------------------------------------ KBD: property checks (parity unpinned)
+# ------------------------------------------------------------------ KBD: property checks (the table itself is pinned in test_reference_golden.py)
 @pytest.mark.parametrize("N", [256, 2048])
 def test_kbd_princen_bradley(N):
     w = window.kbd_table(N)
