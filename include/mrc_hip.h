@@ -171,8 +171,10 @@ int64_t mrc_pack_bound(const mrc_config* cfg, int a, int b, int n_channels, int 
 /* pacfileThem.py:586-613 (file header; num_samples is padded by the reference's inverted test). */
 int mrc_pac_header(const mrc_config* cfg, int n_channels, uint32_t num_samples, uint8_t* out, int64_t out_cap,
                    int64_t* out_len);
-/* Host threads used by mrc_pack_blocks / mrc_pack_joint_blocks (process-wide, default 1). */
+/* Host threads used by mrc_pack_* / mrc_unpack_blocks (process-wide).  Default: the CPUs this process may run on
+ * (sched_getaffinity), at most 16, or $MRC_PACK_THREADS. */
 int mrc_pack_set_threads(int n_threads);
+int mrc_pack_get_threads(void);
 /* What PACFile.WriteDataBlock appends per block (pacfileThem.py:652-790) for n_channels independent
  * channels: per channel `<L nBytes` + MSB-first payload {huffTable:4, blkswA, blkswB, overallScale, band
  * records}.  Arrays: overall_scale [n][nch], scale_factor / bit_alloc [n][nch][nBands], mantissa
@@ -191,6 +193,19 @@ int mrc_pack_joint_blocks(const mrc_config* cfg, int64_t n_blocks, int a, int b,
                           const int32_t* overall_scale, const int32_t* ms_switch, const int32_t* scale_factor,
                           const int32_t* bit_alloc, const int32_t* mantissa, uint8_t* out, int64_t out_cap,
                           int64_t* block_offset, int32_t* huff_table, int32_t* bits_saved);
+
+/* The same bytes with the table of every channel chunk GIVEN (huff_table_in [n][nch], ids 0..3 or 15 = raw) -- e.g.
+ * the choice mrc_dev_huffman_gain already made on the device -- so the host does not price the four tables again
+ * (codecThem.py:151-179); only the recoding and bit packing of codecThem.py:182-200 / pacfileThem.py:716-781,
+ * 892-963 remain.  MRC_ERR_INVALID for an id outside {0..3, 15}. */
+int mrc_pack_blocks_with_tables(const mrc_config* cfg, int64_t n_blocks, int n_channels, int a, int b,
+                                const int32_t* huff_table_in, const int32_t* overall_scale, const int32_t* scale_factor,
+                                const int32_t* bit_alloc, const int32_t* mantissa, uint8_t* out, int64_t out_cap,
+                                int64_t* block_offset);
+int mrc_pack_joint_blocks_with_tables(const mrc_config* cfg, int64_t n_blocks, int a, int b, const int32_t* huff_table_in,
+                                      const int32_t* overall_scale, const int32_t* ms_switch,
+                                      const int32_t* scale_factor, const int32_t* bit_alloc, const int32_t* mantissa,
+                                      uint8_t* out, int64_t out_cap, int64_t* block_offset);
 
 /* Huffman table PRICING on the device (codecThem.py:136-180,202): per (frame, stream) the id of the cheapest
  * table (15 = raw) and bits_saved.  Lets a chained multi-stream encode carry the reservoir from block to block

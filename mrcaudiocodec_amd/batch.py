@@ -114,7 +114,7 @@ class StreamEncoder:
             whole = len(ids) == nS                             # every stream takes this shape: no gather / scatter
             out = self.encode(a, b, flatL, flatR, len(ids), 0, offs, reservoir if whole else reservoir[idx].contiguous(),
                               fresh=True, offsets_checked=True)
-            _, _, nxt = self.huffman_gain(a, b, out, use_huffman)
+            out["huff_table"], _, nxt = self.huffman_gain(a, b, out, use_huffman)    # kept: the packer need not price again
             if whole:
                 reservoir = nxt
             else:

@@ -10,7 +10,10 @@
 // Table ids: sorted table names (percussive 0, silence 1, speech 2, tonal 3), 15 = raw; see DESIGN.md.
 #include "mrc_internal.hpp"
 
+#include <sched.h>
+
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <thread>
@@ -43,6 +46,12 @@ constexpr int kLutSize = 65;        // largest table value is 64
 struct Lut {
     unsigned char len[4][kLutSize];
     unsigned short bits[4][kLutSize];
+    // Pricing all four tables in ONE pass over the mantissas: per value two 64-bit words of four 16-bit fields
+    // (field t = table t): lenSum[v] = code length, 0 where the table has no code for v; miss[v] = 1 there.
+    // A band's sums stay below 2^16 (<= 1024 lines x 9 bits).  Index kLutSize = "any larger value": in no table.
+    uint64_t lenSum[kLutSize + 1], miss[kLutSize + 1];
+    // Emission: emit[t][v] = code | length << 16 | (1 << 31 where the raw mantissa follows: escape value / no code)
+    uint32_t emit[4][kLutSize + 1];
     Lut() {
         std::memset(len, 0, sizeof(len));
         std::memset(bits, 0, sizeof(bits));
@@ -55,27 +64,42 @@ struct Lut {
                 len[t][kTables[t].codes[i].value] = (unsigned char)n;
                 bits[t][kTables[t].codes[i].value] = (unsigned short)v;
             }
+        for (int v = 0; v <= kLutSize; ++v) {
+            lenSum[v] = miss[v] = 0;
+            for (int t = 0; t < 4; ++t) {
+                const int esc = kTables[t].escape;
+                const int n = v < kLutSize ? len[t][v] : 0;
+                lenSum[v] |= (uint64_t)n << (16 * t);
+                miss[v] |= (uint64_t)(n == 0) << (16 * t);
+                if (n != 0 && v != esc) emit[t][v] = bits[t][v] | ((uint32_t)n << 16);
+                else emit[t][v] = bits[t][esc] | ((uint32_t)len[t][esc] << 16) | 0x80000000u;      // codecThem.py:194-200
+            }
+        }
     }
 };
 const Lut kLut;
+inline unsigned lut_index(int32_t v) { return (uint32_t)v < (uint32_t)kLutSize ? (unsigned)v : (unsigned)kLutSize; }
 
 // MSB-first writer, same byte image as bitpack.py:36-101 (zero-initialised buffer, bits OR-ed in)
 struct BitWriter {
     uint8_t* p;
     uint64_t acc = 0;
-    int n = 0;
+    int n = 0;                                        // valid low bits of acc, < 32 between calls
     explicit BitWriter(uint8_t* dst) : p(dst) {}
-    void put(uint32_t info, int nBits) {              // lowest nBits of info
+    void put(uint32_t info, int nBits) {              // lowest nBits (<= 32) of info
         if (nBits <= 0) return;
-        uint64_t v = nBits >= 32 ? info : (info & ((1u << nBits) - 1u));
+        const uint64_t v = nBits >= 32 ? info : (info & ((1u << nBits) - 1u));
         acc = (acc << nBits) | v;
         n += nBits;
-        while (n >= 8) {
-            *p++ = (uint8_t)(acc >> (n - 8));
-            n -= 8;
+        if (n >= 32) {                                // four whole bytes, most significant first
+            const uint32_t w = (uint32_t)(acc >> (n - 32));
+            p[0] = (uint8_t)(w >> 24); p[1] = (uint8_t)(w >> 16); p[2] = (uint8_t)(w >> 8); p[3] = (uint8_t)w;
+            p += 4;
+            n -= 32;
         }
     }
     void flush() {
+        while (n >= 8) { *p++ = (uint8_t)(acc >> (n - 8)); n -= 8; }
         if (n > 0) { *p++ = (uint8_t)(acc << (8 - n)); n = 0; }
     }
 };
@@ -89,34 +113,60 @@ struct ChannelPlan {
 // codecThem.py:136-203.  The price of a table counts the escape VALUE itself as its code only
 // (lines 169-172) although the writer emits code + raw mantissa for it (194-200): kept, so the choice and
 // bits_saved equal the reference's; mantBits is what is really written (pacfileThem.py:685-703).
-ChannelPlan plan_channel(const int32_t* ba, const int32_t* mant, const std::vector<int>& nLines, int useHuffman) {
+int64_t written_bits(const int32_t* ba, const int32_t* mant, const std::vector<int>& nLines, int t) {
+    // what the writer emits for table t (pacfileThem.py:685-703): code, plus the raw mantissa after an escape code
+    const int nb = (int)nLines.size();
+    int64_t written = 0;
+    int k = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int n = nLines[b];
+        if (ba[b]) {
+            int64_t codeBits = 0, rawFollows = 0;
+            for (int i = 0; i < n; ++i) {
+                const uint32_t e = kLut.emit[t][lut_index(mant[k + i])];
+                codeBits += (e >> 16) & 0x7fffu;
+                rawFollows += e >> 31;
+            }
+            written += codeBits + rawFollows * ba[b];
+        }
+        k += n;
+    }
+    return written;
+}
+
+ChannelPlan plan_channel(const int32_t* ba, const int32_t* mant, const std::vector<int>& nLines, int useHuffman,
+                         int givenTable = -1) {
     const int nb = (int)nLines.size();
     int64_t raw = 0;
     for (int b = 0; b < nb; ++b)
         if (ba[b]) raw += (int64_t)ba[b] * nLines[b];
     ChannelPlan plan{kRawTable, raw, 0};
-    if (!useHuffman) return plan;
-    int64_t best = raw;
-    for (int t = 0; t < 4; ++t) {
-        const int esc = kTables[t].escape;
-        const int escLen = kLut.len[t][esc];
-        int64_t priced = 0, written = 0;
-        int k = 0;
-        for (int b = 0; b < nb; ++b) {
-            const int n = nLines[b];
-            if (ba[b]) {
-                for (int i = 0; i < n; ++i) {
-                    const int32_t v = mant[k + i];
-                    const int len = (v >= 0 && v < kLutSize) ? kLut.len[t][v] : 0;
-                    if (len == 0) { priced += ba[b] + escLen; written += ba[b] + escLen; }
-                    else if (v == esc) { priced += len; written += len + ba[b]; }
-                    else { priced += len; written += len; }
-                }
-            }
-            k += n;
-        }
-        if (priced < best) { best = priced; plan.table = t; plan.mantBits = written; }
+    if (givenTable >= 0) {                           // the table was chosen elsewhere (huffman_gain_kernel): no pricing
+        if (givenTable != kRawTable) { plan.table = givenTable; plan.mantBits = written_bits(ba, mant, nLines, givenTable); }
+        return plan;
     }
+    if (!useHuffman) return plan;
+    int64_t priced[4] = {0, 0, 0, 0};
+    int k = 0;
+    for (int b = 0; b < nb; ++b) {
+        const int n = nLines[b];
+        if (ba[b]) {
+            uint64_t lens = 0, misses = 0;           // four 16-bit sums each
+            for (int i = 0; i < n; ++i) {
+                const unsigned idx = lut_index(mant[k + i]);
+                lens += kLut.lenSum[idx];
+                misses += kLut.miss[idx];
+            }
+            for (int t = 0; t < 4; ++t)
+                priced[t] += (int64_t)((lens >> (16 * t)) & 0xffffu) +
+                             (int64_t)((misses >> (16 * t)) & 0xffffu) * (ba[b] + kLut.len[t][kTables[t].escape]);
+        }
+        k += n;
+    }
+    int64_t best = raw;
+    for (int t = 0; t < 4; ++t)
+        if (priced[t] < best) { best = priced[t]; plan.table = t; }
+    if (plan.table != kRawTable) plan.mantBits = written_bits(ba, mant, nLines, plan.table);
     plan.bitsSaved = (int)(raw - best);
     return plan;
 }
@@ -126,20 +176,23 @@ void write_band_records(BitWriter& w, const mrc_config& cfg, const int32_t* sf, 
     const int nb = (int)nLines.size();
     int k = 0;
     for (int b = 0; b < nb; ++b) {
-        w.put((uint32_t)(ba[b] ? ba[b] - 1 : 0), cfg.n_mant_size_bits);      // pacfileThem.py:730-732
-        w.put((uint32_t)sf[b], cfg.n_scale_bits);
+        const int bits = ba[b];
+        // pacfileThem.py:730-732: bit allocation (stored one lower) and scale factor, one put
+        w.put(((uint32_t)(bits ? bits - 1 : 0) << cfg.n_scale_bits) | ((uint32_t)sf[b] & ((1u << cfg.n_scale_bits) - 1u)),
+              cfg.n_mant_size_bits + cfg.n_scale_bits);
         const int n = nLines[b];
-        if (ba[b]) {
-            for (int i = 0; i < n; ++i) {
-                const int32_t v = mant[k + i];
-                if (table == kRawTable) { w.put((uint32_t)v, ba[b]); continue; }
-                const int esc = kTables[table].escape;
-                const int len = (v >= 0 && v < kLutSize) ? kLut.len[table][v] : 0;
-                if (len != 0 && v != esc) {
-                    w.put(kLut.bits[table][v], len);
-                } else {                                                      // codecThem.py:194-200
-                    w.put(kLut.bits[table][esc], kLut.len[table][esc]);
-                    w.put((uint32_t)v, ba[b]);
+        if (bits) {
+            const int32_t* m = mant + k;
+            if (table == kRawTable) {
+                for (int i = 0; i < n; ++i) w.put((uint32_t)m[i], bits);
+            } else {
+                const uint32_t* emit = kLut.emit[table];
+                const uint32_t rawMask = (1u << bits) - 1u;            // bits <= 16
+                for (int i = 0; i < n; ++i) {
+                    const uint32_t e = emit[lut_index(m[i])];
+                    const int len = (int)((e >> 16) & 0x7fffu);
+                    if (e >> 31) w.put(((e & 0xffffu) << bits) | ((uint32_t)m[i] & rawMask), len + bits);   // code + raw: <= 9 + 16 bits
+                    else w.put(e & 0xffffu, len);
                 }
             }
         }
@@ -147,7 +200,20 @@ void write_band_records(BitWriter& w, const mrc_config& cfg, const int32_t* sf, 
     }
 }
 
-std::atomic<int> g_packThreads{1};
+// Worker threads of the packer / parser: the CPUs this process may run on, at most 16 (one GPU's share of a
+// host), MRC_PACK_THREADS or mrc_pack_set_threads() override.
+int default_pack_threads() {
+    if (const char* e = std::getenv("MRC_PACK_THREADS")) {
+        const int v = std::atoi(e);
+        if (v >= 1 && v <= 1024) return v;
+    }
+    int n = 0;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    return n < 1 ? 1 : n > 16 ? 16 : n;
+}
+std::atomic<int> g_packThreads{default_pack_threads()};
 
 // contiguous ranges over up to g_packThreads host threads (1 = run inline)
 template <class F> void parallel_for(int64_t n, F body) {
@@ -222,7 +288,8 @@ bool read_band_records(BitReader& r, const mrc_config& cfg, int table, const std
     for (size_t band = 0; band < bandN.size(); ++band) {
         int bits = (int)r.get(cfg.n_mant_size_bits);
         if (bits) ++bits;
-        ba[band] = bits;
+        if (bits > 16) return false;              // the encoder never allocates more (codecThem.py:292-293); also the
+        ba[band] = bits;                          // reader's and the dequantiser's shifts are only defined up to there
         sf[band] = (int32_t)r.get(cfg.n_scale_bits);
         if (bits) {
             for (int j = 0; j < bandN[band]; ++j) {
@@ -298,7 +365,8 @@ int mrc_pac_header(const mrc_config* cfg, int n_channels, uint32_t num_samples, 
 static int pack_blocks(const mrc_config* cfg, int64_t n, int nch, int a, int b, int joint, int use_huffman,
                        const int32_t* overall_scale, const int32_t* ms_switch, const int32_t* scale_factor,
                        const int32_t* bit_alloc, const int32_t* mantissa, uint8_t* out, int64_t out_cap,
-                       int64_t* block_offset, int32_t* huff_table, int32_t* bits_saved) {
+                       int64_t* block_offset, int32_t* huff_table, int32_t* bits_saved,
+                       const int32_t* huff_table_in = nullptr) {
     if (!shape_ok(cfg, a, b) || n < 0 || !overall_scale || !scale_factor || !bit_alloc || !mantissa || !out ||
         !block_offset || (joint && (!ms_switch || nch != 2)) || nch < 1)
         return MRC_ERR_INVALID;
@@ -313,9 +381,15 @@ static int pack_blocks(const mrc_config* cfg, int64_t n, int nch, int a, int b, 
     const int64_t nChunks = n * nch;
     std::vector<ChannelPlan> plans((size_t)nChunks);
     std::vector<int64_t> chunkBytes((size_t)nChunks);
+    std::atomic<int> badTable{0};
     parallel_for(nChunks, [&](int64_t c) {
         const int ch = (int)(c % nch);
-        const ChannelPlan plan = plan_channel(bit_alloc + c * nb, mantissa + c * (int64_t)half, nLines, use_huffman);
+        int given = -1;
+        if (huff_table_in) {
+            given = huff_table_in[c];
+            if (given != kRawTable && (given < 0 || given > 3)) { badTable.store(1); given = kRawTable; }
+        }
+        const ChannelPlan plan = plan_channel(bit_alloc + c * nb, mantissa + c * (int64_t)half, nLines, use_huffman, given);
         int64_t bits = 4 + cfg->blksw_bits_a + cfg->blksw_bits_b + (int64_t)nb * (cfg->n_mant_size_bits + cfg->n_scale_bits) +
                        plan.mantBits;
         if (joint) { if (ch == 0) bits += nb + 4 * cfg->n_scale_bits; }           // pacfileThem.py:826-833
@@ -325,6 +399,7 @@ static int pack_blocks(const mrc_config* cfg, int64_t n, int nch, int a, int b, 
         if (huff_table) huff_table[c] = plan.table;
         if (bits_saved) bits_saved[c] = plan.bitsSaved;
     });
+    if (badTable.load()) return MRC_ERR_INVALID;
     std::vector<int64_t> chunkPos((size_t)nChunks + 1);
     int64_t pos = 0;
     for (int64_t c = 0; c < nChunks; ++c) {
@@ -383,6 +458,26 @@ int mrc_pack_joint_blocks(const mrc_config* cfg, int64_t n_blocks, int a, int b,
                        mantissa, out, out_cap, block_offset, huff_table, bits_saved);
 }
 
+int mrc_pack_blocks_with_tables(const mrc_config* cfg, int64_t n_blocks, int n_channels, int a, int b,
+                                const int32_t* huff_table_in, const int32_t* overall_scale, const int32_t* scale_factor,
+                                const int32_t* bit_alloc, const int32_t* mantissa, uint8_t* out, int64_t out_cap,
+                                int64_t* block_offset) {
+    if (!huff_table_in) return MRC_ERR_INVALID;
+    return pack_blocks(cfg, n_blocks, n_channels, a, b, 0, 1, overall_scale, nullptr, scale_factor, bit_alloc, mantissa,
+                       out, out_cap, block_offset, nullptr, nullptr, huff_table_in);
+}
+
+int mrc_pack_joint_blocks_with_tables(const mrc_config* cfg, int64_t n_blocks, int a, int b, const int32_t* huff_table_in,
+                                      const int32_t* overall_scale, const int32_t* ms_switch,
+                                      const int32_t* scale_factor, const int32_t* bit_alloc, const int32_t* mantissa,
+                                      uint8_t* out, int64_t out_cap, int64_t* block_offset) {
+    if (!huff_table_in) return MRC_ERR_INVALID;
+    return pack_blocks(cfg, n_blocks, 2, a, b, 1, 1, overall_scale, ms_switch, scale_factor, bit_alloc, mantissa, out,
+                       out_cap, block_offset, nullptr, nullptr, huff_table_in);
+}
+
+int mrc_pack_get_threads(void) { return g_packThreads.load(); }
+
 
 // ---- decode side ---------------------------------------------------------------------------------------------
 int mrc_pac_read_header(const uint8_t* buf, int64_t len, mrc_config* cfg, int32_t* n_channels, uint32_t* num_samples,
@@ -397,6 +492,11 @@ int mrc_pac_read_header(const uint8_t* buf, int64_t len, mrc_config* cfg, int32_
     cfg->n_mant_size_bits = (int32_t)get_u16le(buf + 20);
     const uint32_t nBands = get_u32le(buf + 22);
     if (nBands > 4096 || 26 + 2 * (int64_t)nBands > len) return MRC_ERR_INVALID;
+    // the header is untrusted input and sizes every later allocation: refuse what no encoder writes
+    if (cfg->sample_rate <= 0 || *n_channels < 1 || *n_channels > 2 || cfg->n_mdct_lines < 16 ||
+        cfg->n_mdct_lines > 8192 || (cfg->n_mdct_lines & (cfg->n_mdct_lines - 1)) != 0 || cfg->n_scale_bits < 1 ||
+        cfg->n_scale_bits > 4 || cfg->n_mant_size_bits < 1 || cfg->n_mant_size_bits > 8)
+        return MRC_ERR_INVALID;
     *data_offset = 26 + 2 * (int64_t)nBands;           // the band table itself is implied by rate and block length
     return MRC_OK;
 }

@@ -35,8 +35,13 @@ def make_config(sample_rate=48000, n_mdct_lines=1024, n_short=128, n_scale_bits=
 
 
 def set_threads(n):
-    """Host threads the C++ packer uses for a batch of blocks (process-wide, default 1)."""
+    """Host threads the C++ packer / parser uses for a batch of blocks (process-wide; default: the CPUs the process
+    may run on, at most 16, or $MRC_PACK_THREADS)."""
     _check(lib.mrc_pack_set_threads(int(n)), "mrc_pack_set_threads")
+
+
+def get_threads():
+    return int(lib.mrc_pack_get_threads())
 
 
 def _check(rc, what):
@@ -63,12 +68,15 @@ def header(cfg, n_channels, num_samples):
     return out[:n.value].tobytes()
 
 
-def _run_pack(fn, cfg, n, nch, a, b, joint, args):
+def _run_pack(fn, cfg, n, nch, a, b, joint, args, given_tables=None):
     bound = lib.mrc_pack_bound(C.byref(cfg), int(a), int(b), nch, int(joint))
     if bound < 0:
         raise MrcError("mrc_pack_bound failed (%d)" % bound)
-    out = np.zeros(max(1, n * bound), dtype=np.uint8)
+    out = np.empty(max(1, n * bound), dtype=np.uint8)          # every byte up to offs[n] is written by the packer
     offs = np.zeros(n + 1, dtype=np.int64)
+    if given_tables is not None:
+        _check(fn(*args, out.ctypes.data_as(_u8p), out.size, offs.ctypes.data_as(_i64p)), fn.__name__)
+        return out[:offs[n]], offs, given_tables, None
     table = np.zeros((n, nch), dtype=np.int32)
     saved = np.zeros((n, nch), dtype=np.int32)
     _check(fn(*args, out.ctypes.data_as(_u8p), out.size, offs.ctypes.data_as(_i64p), table.ctypes.data_as(_i32p),
@@ -76,23 +84,36 @@ def _run_pack(fn, cfg, n, nch, a, b, joint, args):
     return out[:offs[n]], offs, table, saved
 
 
-def pack_blocks(cfg, a, b, overall_scale, scale_factor, bit_alloc, mantissa, use_huffman=True):
+def pack_blocks(cfg, a, b, overall_scale, scale_factor, bit_alloc, mantissa, use_huffman=True, huff_table=None):
     """WriteDataBlock for n blocks of nch independent channels.  overall_scale [n][nch], scale_factor /
     bit_alloc [n][nch][nBands], mantissa [n][nch][N/2] dense.  -> (bytes array, block offsets [n+1],
-    huffTable [n][nch], bits_saved [n][nch])."""
+    huffTable [n][nch], bits_saved [n][nch]).  huff_table [n][nch] given (e.g. by Handle.dev_huffman_gain): the
+    host skips the pricing of the four tables and bits_saved is None."""
     sf, ba, m = _i32(scale_factor), _i32(bit_alloc), _i32(mantissa)
     osc = _i32(overall_scale)
     n, nch = sf.shape[0], sf.shape[1]
+    if huff_table is not None:
+        ht = _i32(huff_table).reshape(n, nch)
+        args = (C.byref(cfg), n, nch, int(a), int(b), ht.ctypes.data_as(_i32p), osc.ctypes.data_as(_i32p),
+                sf.ctypes.data_as(_i32p), ba.ctypes.data_as(_i32p), m.ctypes.data_as(_i32p))
+        return _run_pack(lib.mrc_pack_blocks_with_tables, cfg, n, nch, a, b, 0, args, given_tables=ht)
     args = (C.byref(cfg), n, nch, int(a), int(b), int(bool(use_huffman)), osc.ctypes.data_as(_i32p),
             sf.ctypes.data_as(_i32p), ba.ctypes.data_as(_i32p), m.ctypes.data_as(_i32p))
     return _run_pack(lib.mrc_pack_blocks, cfg, n, nch, a, b, 0, args)
 
 
-def pack_joint_blocks(cfg, a, b, overall_scale, ms_switch, scale_factor, bit_alloc, mantissa, use_huffman=True):
-    """JointWriteDataBlock for n blocks.  overall_scale [n][4], ms_switch [n][nBands], others [n][2][...]."""
+def pack_joint_blocks(cfg, a, b, overall_scale, ms_switch, scale_factor, bit_alloc, mantissa, use_huffman=True,
+                      huff_table=None):
+    """JointWriteDataBlock for n blocks.  overall_scale [n][4], ms_switch [n][nBands], others [n][2][...];
+    huff_table [n][2] as in pack_blocks."""
     sf, ba, m = _i32(scale_factor), _i32(bit_alloc), _i32(mantissa)
     osc, sw = _i32(overall_scale), _i32(ms_switch)
     n = sf.shape[0]
+    if huff_table is not None:
+        ht = _i32(huff_table).reshape(n, 2)
+        args = (C.byref(cfg), n, int(a), int(b), ht.ctypes.data_as(_i32p), osc.ctypes.data_as(_i32p),
+                sw.ctypes.data_as(_i32p), sf.ctypes.data_as(_i32p), ba.ctypes.data_as(_i32p), m.ctypes.data_as(_i32p))
+        return _run_pack(lib.mrc_pack_joint_blocks_with_tables, cfg, n, 2, a, b, 1, args, given_tables=ht)
     args = (C.byref(cfg), n, int(a), int(b), int(bool(use_huffman)), osc.ctypes.data_as(_i32p), sw.ctypes.data_as(_i32p),
             sf.ctypes.data_as(_i32p), ba.ctypes.data_as(_i32p), m.ctypes.data_as(_i32p))
     return _run_pack(lib.mrc_pack_joint_blocks, cfg, n, 2, a, b, 1, args)
@@ -166,7 +187,7 @@ def encode_stereo_streams(handle, streams, shapes, use_huffman=True, num_samples
     closing = []
     for ch in range(2):
         out = enc.encode(L, L, flush[ch].reshape(-1), None, nS, 2 * L, None, reservoir.contiguous(), fresh=True)
-        _, _, reservoir = enc.huffman_gain(L, L, out, use_huffman)
+        out["huff_table"], _, reservoir = enc.huffman_gain(L, L, out, use_huffman)
         closing.append(out)
     torch.cuda.synchronize(dev)
 
@@ -174,14 +195,15 @@ def encode_stereo_streams(handle, streams, shapes, use_huffman=True, num_samples
              for s, sh in enumerate(shapes)]
     host = lambda o, k: o[k].cpu().numpy()
     for ids, a, b, out in steps:
+        # the table of every chunk was chosen on the device (huffman_gain_kernel): the host only recodes and packs
         data, offs, _, _ = pack_joint_blocks(cfg, a, b, host(out, "overall_scale"), host(out, "ms_switch"),
                                              host(out, "scale_factor"), host(out, "bit_alloc"), host(out, "mantissa"),
-                                             use_huffman)
+                                             huff_table=host(out, "huff_table"))
         for i, s in enumerate(ids):
             parts[s].append(data[offs[i]:offs[i + 1]].tobytes())
     for out in closing:
         data, offs, _, _ = pack_blocks(cfg, L, L, host(out, "overall_scale"), host(out, "scale_factor"),
-                                       host(out, "bit_alloc"), host(out, "mantissa"), use_huffman)
+                                       host(out, "bit_alloc"), host(out, "mantissa"), huff_table=host(out, "huff_table"))
         for s in range(nS):
             parts[s].append(data[offs[s]:offs[s + 1]].tobytes())
     return [b"".join(p) for p in parts]

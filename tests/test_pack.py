@@ -79,12 +79,15 @@ def test_pack_threads_give_identical_bytes():
     r = fast.encode_joint_batch(bl, br, 1024, 1024)
     cfg = ppac.make_config()
     args = (cfg, 1024, 1024, r["overall_scale"], r["ms_switch"], r["scale_factor"], r["bit_alloc"], r["mantissa"])
-    one = ppac.pack_joint_blocks(*args)
+    before = ppac.get_threads()
+    assert 1 <= before <= 16                                   # default: the CPUs of the process, at most 16
     try:
+        ppac.set_threads(1)
+        one = ppac.pack_joint_blocks(*args)
         ppac.set_threads(5)
         many = ppac.pack_joint_blocks(*args)
     finally:
-        ppac.set_threads(1)
+        ppac.set_threads(before)
     assert one[0].tobytes() == many[0].tobytes() and np.array_equal(one[1], many[1])
     assert np.array_equal(one[2], many[2]) and np.array_equal(one[3], many[3])
 
@@ -107,3 +110,43 @@ def test_pack_escape_and_buffer_checks():
     from mrcaudiocodec_amd._lib import lib, MrcError
     with pytest.raises(MrcError):
         ppac.band_table(cfg, 0, 5)
+
+
+def test_pack_with_given_tables_equals_priced():
+    """mrc_pack_*_with_tables: the table ids chosen elsewhere (on the device by huffman_gain_kernel) give the same
+    bytes as the host's own pricing; any valid id packs (forced tables), an invalid one is refused."""
+    t = synth.c1_sine(8)
+    n = synth.c3_stereo(8)
+    s = np.stack([t + 0.01 * n[0], 0.9 * t + 1e-4 * n[1]])
+    bl, br = np.array(fast.blocks_from_stream(s[0], 1024)), np.array(fast.blocks_from_stream(s[1], 1024))
+    r = fast.encode_joint_batch(bl, br, 1024, 1024)
+    cfg = ppac.make_config()
+    args = (cfg, 1024, 1024, r["overall_scale"], r["ms_switch"], r["scale_factor"], r["bit_alloc"], r["mantissa"])
+    data, offs, table, _ = ppac.pack_joint_blocks(*args, use_huffman=True)
+    assert (table != 15).any()
+    given = ppac.pack_joint_blocks(*args, huff_table=table)
+    assert given[0].tobytes() == data.tobytes() and np.array_equal(given[1], offs)
+    raw = ppac.pack_joint_blocks(*args, use_huffman=False)
+    assert ppac.pack_joint_blocks(*args, huff_table=np.full_like(table, 15))[0].tobytes() == raw[0].tobytes()
+    # a forced table (not the cheapest): still what the oracle's writer emits for that table id
+    cp = _cp(2, 1024, 1024)
+    forced = np.full_like(table, 2)
+    got = ppac.pack_joint_blocks(*args, huff_table=forced)
+    from oracle.huffman_tables import TABLES, TABLE_ORDER
+    tab, esc = TABLES[TABLE_ORDER[2]]
+    for i in range(bl.shape[0]):
+        ms = []
+        for c in range(2):
+            m = fast.compact_mantissa(r["mantissa"][i, c], r["bit_alloc"][i, c], cp.sfBands)
+            ms.append([tab[int(v)][0] if (int(v) in tab and int(v) != esc) else tab[esc][0] + "/" + str(int(v)) for v in m])
+        want = opac.pack_joint_block(list(r["scale_factor"][i]), list(r["bit_alloc"][i]), ms,
+                                     [int(v) for v in r["overall_scale"][i]], list(r["ms_switch"][i]), [2, 2], cp)
+        assert got[0][got[1][i]:got[1][i + 1]].tobytes() == want, i
+    mono = fast.encode_mono_batch(bl, 1024, 1024)
+    margs = (cfg, 1024, 1024, mono["overall_scale"][:, None], mono["scale_factor"][:, None, :], mono["bit_alloc"][:, None, :],
+             mono["mantissa"][:, None, :])
+    d1, o1, t1, _ = ppac.pack_blocks(*margs, use_huffman=True)
+    assert ppac.pack_blocks(*margs, huff_table=t1)[0].tobytes() == d1.tobytes()
+    from mrcaudiocodec_amd._lib import MrcError
+    with pytest.raises(MrcError):
+        ppac.pack_joint_blocks(*args, huff_table=np.full_like(table, 7))

@@ -70,6 +70,38 @@ def test_unpack_rejects_damaged_input():
         ppac.unpack_blocks(cfg, bytes(bad), chunks[:2], 2, True)
 
 
+def test_unpack_rejects_crafted_headers_and_widths():
+    """The file header sizes allocations and picks field widths: values no encoder writes are refused (a crafted
+    nMantSizeBits >= 5 would otherwise reach 17..256-bit mantissa reads and shifts)."""
+    import struct
+    stream, shapes = _stream(4, False)
+    pac = opac.encode_stereo_stream(stream, shapes, huffman=False)
+
+    def patched(offset, fmt, value):
+        b = bytearray(pac)
+        b[offset:offset + struct.calcsize(fmt)] = struct.pack(fmt, value)
+        return bytes(b)
+    # header: "PAC " <L rate <H nCh <L numSamples <L nMDCTLines <H nScaleBits <H nMantSizeBits <L nBands
+    for off, fmt, value in ((4, "<L", 0), (8, "<H", 0), (8, "<H", 3), (14, "<L", 0), (14, "<L", 1000), (14, "<L", 1 << 20),
+                            (18, "<H", 0), (18, "<H", 9), (20, "<H", 0), (20, "<H", 9)):
+        with pytest.raises(ppac.MrcError):
+            ppac.read_header(patched(off, fmt, value))
+    # nMantSizeBits = 5 is a legal header (the training script used it) but lets a chunk claim up to 32 mantissa bits
+    # per line; more than 16 is refused by the band-record reader
+    cfg, nch, _, off = ppac.read_header(patched(20, "<H", 5))
+    assert cfg.n_mant_size_bits == 5
+    chunks = ppac.scan_chunks(pac, off)
+    bad = bytearray(patched(20, "<H", 5))
+    # first band record of chunk 0 starts after table(4) + blksw(2) + 4 overall scales(16) + 25 M/S bits = bit 47
+    first = chunks[0] + 4
+    bits = 47
+    for i in range(5):                                         # bit allocation field := 0b11111 -> ba = 32
+        byte, bit = first + (bits + i) // 8, 7 - (bits + i) % 8
+        bad[byte] |= 1 << bit
+    with pytest.raises(ppac.MrcError):
+        ppac.unpack_blocks(cfg, bytes(bad), chunks[:2], 2, True)
+
+
 @pytest.mark.parametrize("shape", [(1024, 1024), (128, 128), (1024, 128), (128, 1024)])
 @pytest.mark.parametrize("huff", [False, True])
 def test_pack_unpack_round_trip_random_blocks(shape, huff):
