@@ -37,8 +37,14 @@
 extern "C" {
 #endif
 
-#define MRC_VERSION 100            /* 0.1.0 */
+#define MRC_VERSION 200            /* 0.2.0 */
 #define MRC_MAX_BANDS 32
+/* how a channel's samples are held: float64 signed fractions (what pcmfile.py:98 hands the codec) or the file's
+ * int16 PCM codes (converted on load, pcmfile.py:91-100); how the mantissa plane is stored */
+#define MRC_SAMPLES_F64 0
+#define MRC_SAMPLES_PCM16 1
+#define MRC_MANTISSA_I32 0
+#define MRC_MANTISSA_I16 1         /* uint16: a code is sign bit + magnitude in at most 16 bits (codecThem.py:292-293) */
 
 typedef enum mrc_status {
     MRC_OK = 0,
@@ -92,6 +98,41 @@ int mrc_encode_joint(mrc_handle* h, int64_t n_blocks, int a, int b, const double
                      int32_t* overall_scale, int32_t* ms_switch, int32_t* scale_factor, int32_t* bit_alloc,
                      int32_t* mantissa, int32_t* reservoir_out, double* mdct_out);
 
+/* The same for n_blocks blocks of MIXED shapes in one call -- a block-switched stream as pacfileThem.py:1192-1210
+ * produces it -- so that a binding without array libraries can hand over a whole stream: `blocks` (left / right) is
+ * the blocks packed back to back, block i holding a[i] + b[i] samples; SURVEY.md 8(b) `a[]`, `b[]`.  Blocks are grouped
+ * by shape inside (one launch set per distinct shape); reservoir_in [n] may be NULL.  Because the shape varies, the
+ * outputs have fixed strides: scale_factor / bit_alloc [n][streams][MRC_MAX_BANDS], ms_switch [n][MRC_MAX_BANDS],
+ * mantissa [n][streams][n_mdct_lines] dense (entries beyond a block's band / line count are 0), overall_scale
+ * [n] (mono) / [n][4] (joint). */
+int mrc_encode_mono_blocks(mrc_handle* h, int64_t n_blocks, const double* blocks, const int32_t* a, const int32_t* b,
+                           const int32_t* reservoir_in, int32_t* overall_scale, int32_t* scale_factor,
+                           int32_t* bit_alloc, int32_t* mantissa, int32_t* reservoir_out);
+int mrc_encode_joint_blocks(mrc_handle* h, int64_t n_blocks, const double* left, const double* right, const int32_t* a,
+                            const int32_t* b, const int32_t* reservoir_in, int32_t* overall_scale, int32_t* ms_switch,
+                            int32_t* scale_factor, int32_t* bit_alloc, int32_t* mantissa, int32_t* reservoir_out);
+
+/* ---- the file's own sample format in, compact codes out: what a WAV -> .pac pipeline moves over PCIe ----------
+ * A long-block stream from 16-bit PCM codes in HOST memory to codes in HOST memory, pipelined: pcm_left (and
+ * pcm_right: joint stereo) hold (n_frames + 1) * n_mdct_lines int16 samples, hop-overlapped (frame f = samples
+ * [f * L, f * L + 2 L); the first hop is the prior block, zeros at file start: pacfileThem.py:615-631).  The codes
+ * are converted on load exactly as pcmfile.py:91-100 does (x = 2c/65535 correctly rounded, -32768 -> 0.0).
+ * Frames are independent given reservoir_in [n] (NULL = zeros).  Outputs as mrc_encode_mono / _joint for a = b = L,
+ * except the mantissa plane, which is uint16 [n][streams][L] (codes are at most 16 bits wide, codecThem.py:292-293).
+ * The work is cut into chunks of chunk_frames frames (0: 16384); chunk i's upload, kernels and download are queued
+ * on one of three HIP streams, so the copies of neighbouring chunks run beside its kernels.  With host buffers from
+ * mrc_host_alloc / mrc_host_register (page-locked) the copies are truly asynchronous; pageable buffers work, slower.
+ * PCIe bytes per (frame, channel): 2 048 in, 2 048 + 2 * 4 * nBands + 8 (+ 4 * nBands per joint frame) out. */
+int mrc_encode_stream_pcm16(mrc_handle* h, int64_t n_frames, const int16_t* pcm_left, const int16_t* pcm_right,
+                            const int32_t* reservoir_in, int32_t* overall_scale, int32_t* ms_switch,
+                            int32_t* scale_factor, int32_t* bit_alloc, uint16_t* mantissa16, int32_t* reservoir_out,
+                            int64_t chunk_frames);
+/* Page-locked host memory (hipHostMalloc / hipHostRegister): no handle needed, any thread. */
+int mrc_host_alloc(void** out, size_t bytes);
+int mrc_host_free(void* p);
+int mrc_host_register(void* p, size_t bytes);
+int mrc_host_unregister(void* p);
+
 /* ---- stage-level host entry points (parity tests against the reference's own modules) ---------- */
 
 /* window.py:104-121 (TransitionWindow; KBDWindow when a == b): out[n_blocks][a+b] = blocks * window. */
@@ -111,12 +152,24 @@ int mrc_smr(mrc_handle* h, int64_t n_blocks, int a, int b, const double* blocks,
  * bits [n_cases][n_bands], bits_left [n_cases] (int(bitsLeft), truncated toward zero). */
 int mrc_bitalloc(mrc_handle* h, int64_t n_cases, int n_bands, int max_mant_bits, const int32_t* n_lines,
                  const double* budget, const double* smr, int32_t* bits, int32_t* bits_left);
+/* The same with bitalloc.py:132-151's SIDE EFFECT: smr [n_cases][n_bands] is overwritten with the running values the
+ * loop leaves behind (-12 for a band's first grant, -6 per further bit, -99999999999999999.0 once retired). */
+int mrc_bitalloc_inplace(mrc_handle* h, int64_t n_cases, int n_bands, int max_mant_bits, const int32_t* n_lines,
+                         const double* budget, double* smr, int32_t* bits, int32_t* bits_left);
 /* quantize.py:114-146 elementwise: scale[i] = ScaleFactor(v[i], n_scale_bits, n_mant_bits[i]). */
 int mrc_scale_factor(mrc_handle* h, int64_t n, int n_scale_bits, const double* v, const int32_t* n_mant_bits,
                      int32_t* scale);
 /* quantize.py:294-322 elementwise: mant[i] = vMantissa([x[i]], scale[i], n_scale_bits, n_mant_bits[i]). */
 int mrc_mantissa(mrc_handle* h, int64_t n, int n_scale_bits, const double* x, const int32_t* scale,
                  const int32_t* n_mant_bits, int32_t* mant);
+/* quantize.py:61-87 (vQuantizeUniform; QuantizeUniform 12-38 is its scalar form) elementwise: code[i] = sign bit <<
+ * (n_bits - 1) + magnitude code of |x[i]|; 1 <= n_bits <= 62. */
+int mrc_quantize_uniform(mrc_handle* h, int64_t n, int n_bits, const double* x, int64_t* code);
+/* psychoac.py:27-29 elementwise: z = 13 atan(0.76 f / 1000) + 3.5 atan((f / 7500)^2). */
+int mrc_bark(mrc_handle* h, int64_t n, const double* f, double* z);
+/* pcmfile.py:91-100 elementwise: out[i] = sign(c) 2|c| / 65535 (one rounding), -32768 -> 0.0 -- the map the PCM16
+ * ingest paths apply on load. */
+int mrc_pcm_to_float(mrc_handle* h, int64_t n, const int16_t* pcm, double* out);
 /* pacfileThem.py:1025-1056 (TransientDetector), numeric part, for every hop of a stream at once: streams is
  * [n_channels][(n_hops+1)*nMDCTLines] (each channel starts with the prior hop); hop i = samples
  * [(i+1)*nMDCTLines, (i+2)*nMDCTLines) is filtered FROM A ZERO STATE (the reference calls sosfilt without zi)
@@ -158,6 +211,12 @@ int mrc_dev_encode(mrc_handle* h, int a, int b, int64_t n_frames, const double* 
                    int64_t frame_stride, const int64_t* offsets, const int32_t* reservoir_in,
                    int32_t* overall_scale, int32_t* ms_switch, int32_t* bit_alloc, int32_t* scale_factor,
                    int32_t* mantissa, int32_t* reservoir_out, double* lines_out, void* stream);
+/* The same with the channel format (MRC_SAMPLES_*: ch_left / ch_right are double* or int16_t*) and the mantissa
+ * plane format (MRC_MANTISSA_*: int32_t* or uint16_t*) chosen by the caller; offsets / frame_stride count samples. */
+int mrc_dev_encode_ex(mrc_handle* h, int a, int b, int64_t n_frames, const void* ch_left, const void* ch_right,
+                      int sample_format, int64_t frame_stride, const int64_t* offsets, const int32_t* reservoir_in,
+                      int32_t* overall_scale, int32_t* ms_switch, int32_t* bit_alloc, int32_t* scale_factor,
+                      void* mantissa, int mantissa_format, int32_t* reservoir_out, double* lines_out, void* stream);
 
 /* ---- host-side back end: Huffman table choice + `.pac` bit packing (no GPU, no handle) -----------
  * BASELINE.json's north_star keeps huffman.py / bitpack.py on the host; these are their C++ form, fed with
@@ -265,6 +324,9 @@ int mrc_set_timing(mrc_handle* h, int enabled);
 #define MRC_OPT_EXACT_SPREAD 1
 int mrc_set_option(mrc_handle* h, int option, int value);
 int mrc_get_stage_ms(mrc_handle* h, double* ms /*[3]*/);
+/* ... and per kernel: ms[0..4] = MDCT, smr_kernel, band_stats_kernel (joint only, else ~0), bitalloc_kernel,
+ * quantize_kernel. */
+int mrc_get_kernel_ms(mrc_handle* h, double* ms /*[5]*/);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,7 @@ def _load():
         "mrc_mdct": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, _f64p, C.c_int, _f64p, _i32p]),
         "mrc_smr": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, _f64p, _f64p, _i32p, _f64p, _f64p]),
         "mrc_bitalloc": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, _i32p, _f64p, _f64p, _i32p, _i32p]),
+        "mrc_bitalloc_inplace": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, _i32p, _f64p, _f64p, _i32p, _i32p]),
         "mrc_scale_factor": (C.c_int, [H, C.c_int64, C.c_int, _f64p, _i32p, _i32p]),
         "mrc_mantissa": (C.c_int, [H, C.c_int64, C.c_int, _f64p, _i32p, _i32p, _i32p]),
         "mrc_transient_peaks": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, _f64p, _f64p, _f64p]),
@@ -82,6 +83,21 @@ def _load():
         "mrc_dev_alloc_quant": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_int] + [C.c_void_p] * 10),
         "mrc_dev_encode": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64] +
                            [C.c_void_p] * 10),
+        "mrc_dev_encode_ex": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int64] +
+                              [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 3),
+        "mrc_encode_mono_blocks": (C.c_int, [H, C.c_int64, _f64p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p]),
+        "mrc_encode_joint_blocks": (C.c_int, [H, C.c_int64, _f64p, _f64p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p, _i32p,
+                                              _i32p, _i32p]),
+        "mrc_encode_stream_pcm16": (C.c_int, [H, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+        "mrc_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+        "mrc_host_free": (C.c_int, [C.c_void_p]),
+        "mrc_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
+        "mrc_host_unregister": (C.c_int, [C.c_void_p]),
+        "mrc_pcm_to_float": (C.c_int, [H, C.c_int64, C.c_void_p, _f64p]),
+        "mrc_quantize_uniform": (C.c_int, [H, C.c_int64, C.c_int, _f64p, _i64p]),
+        "mrc_bark": (C.c_int, [H, C.c_int64, _f64p, _f64p]),
+        "mrc_get_kernel_ms": (C.c_int, [H, _f64p]),
         "mrc_huffman_gain": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p]),
         "mrc_dev_huffman_gain": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_int] + [C.c_void_p] * 7),
         "mrc_pac_read_header": (C.c_int, [_u8p, C.c_int64, C.POINTER(MrcConfig), _i32p, C.POINTER(C.c_uint32), _i64p]),
@@ -125,6 +141,16 @@ def _f64(a):
 
 def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _reservoir(reservoir_in, n):
+    """reservoir_in as int32 [n] (None stays None); the C side reads n values from it."""
+    if reservoir_in is None:
+        return None
+    r = _i32(np.asarray(reservoir_in).reshape(-1))
+    if r.shape != (n,):
+        raise ValueError("reservoir_in must hold one value per block (%d), got %d" % (n, r.size))
+    return r
 
 
 def _p(a, typ):
@@ -195,7 +221,7 @@ class Handle:
         if N != a + b:
             raise ValueError("blocks must be [n][a+b]")
         nb, half = len(self.bands(a, b)), N // 2
-        res_in = None if reservoir_in is None else _i32(reservoir_in)
+        res_in = _reservoir(reservoir_in, n)
         out = dict(overall_scale=np.empty(n, np.int32), scale_factor=np.empty((n, nb), np.int32),
                    bit_alloc=np.empty((n, nb), np.int32), mantissa=np.empty((n, half), np.int32),
                    reservoir_out=np.empty(n, np.int32))
@@ -214,7 +240,7 @@ class Handle:
         if N != a + b or right.shape != left.shape:
             raise ValueError("left/right must be [n][a+b]")
         nb, half = len(self.bands(a, b)), N // 2
-        res_in = None if reservoir_in is None else _i32(reservoir_in)
+        res_in = _reservoir(reservoir_in, n)
         out = dict(overall_scale=np.empty((n, 4), np.int32), ms_switch=np.empty((n, nb), np.int32),
                    scale_factor=np.empty((n, 2, nb), np.int32), bit_alloc=np.empty((n, 2, nb), np.int32),
                    mantissa=np.empty((n, 2, half), np.int32), reservoir_out=np.empty(n, np.int32))
@@ -226,6 +252,93 @@ class Handle:
                                          _p(mdct, _f64p)))
         if want_mdct:
             out["mdct"] = mdct
+        return out
+
+    def encode_blocks(self, left, a, b, right=None, reservoir_in=None):
+        """Blocks of MIXED shapes in one call (mrc_encode_mono_blocks / mrc_encode_joint_blocks): `left` (and `right`)
+        is a list of 1-D arrays, block i holding a[i] + b[i] samples.  Outputs have fixed strides: scale_factor /
+        bit_alloc [n][streams][MRC_MAX_BANDS], ms_switch [n][MRC_MAX_BANDS], mantissa [n][streams][n_mdct_lines]."""
+        a, b = _i32(a), _i32(b)
+        n = len(a)
+        if len(b) != n or len(left) != n or (right is not None and len(right) != n):
+            raise ValueError("one (a, b) pair and one block per entry expected")
+        for i in range(n):
+            if len(left[i]) != a[i] + b[i] or (right is not None and len(right[i]) != a[i] + b[i]):
+                raise ValueError("block %d does not hold a + b = %d samples" % (i, a[i] + b[i]))
+        packed_l = _f64(np.concatenate([np.asarray(x, dtype=np.float64) for x in left])) if n else np.zeros(0)
+        res_in = _reservoir(reservoir_in, n)
+        L = self.cfg.n_mdct_lines
+        ns, nsig = (2, 4) if right is not None else (1, 1)
+        out = dict(overall_scale=np.empty((n, nsig) if right is not None else n, np.int32),
+                   scale_factor=np.empty((n, ns, MRC_MAX_BANDS), np.int32), bit_alloc=np.empty((n, ns, MRC_MAX_BANDS), np.int32),
+                   mantissa=np.empty((n, ns, L), np.int32), reservoir_out=np.empty(n, np.int32))
+        if right is None:
+            self._check(lib.mrc_encode_mono_blocks(self._h, n, _p(packed_l, _f64p), _p(a, _i32p), _p(b, _i32p),
+                                                   _p(res_in, _i32p), _p(out["overall_scale"], _i32p),
+                                                   _p(out["scale_factor"], _i32p), _p(out["bit_alloc"], _i32p),
+                                                   _p(out["mantissa"], _i32p), _p(out["reservoir_out"], _i32p)))
+        else:
+            packed_r = _f64(np.concatenate([np.asarray(x, dtype=np.float64) for x in right])) if n else np.zeros(0)
+            out["ms_switch"] = np.empty((n, MRC_MAX_BANDS), np.int32)
+            self._check(lib.mrc_encode_joint_blocks(self._h, n, _p(packed_l, _f64p), _p(packed_r, _f64p), _p(a, _i32p),
+                                                    _p(b, _i32p), _p(res_in, _i32p), _p(out["overall_scale"], _i32p),
+                                                    _p(out["ms_switch"], _i32p), _p(out["scale_factor"], _i32p),
+                                                    _p(out["bit_alloc"], _i32p), _p(out["mantissa"], _i32p),
+                                                    _p(out["reservoir_out"], _i32p)))
+        return out
+
+    def encode_stream_pcm16(self, pcm_left, pcm_right=None, reservoir_in=None, chunk_frames=0, out=None):
+        """mrc_encode_stream_pcm16: int16 PCM stream(s) [(n+1) * L] in host memory -> codes in host memory, long
+        blocks, pipelined over three HIP streams.  `out` may hold preallocated (ideally page-locked, see
+        pinned_empty) arrays to write into; the mantissa plane is uint16."""
+        L = self.cfg.n_mdct_lines
+        pl = np.ascontiguousarray(pcm_left, dtype=np.int16)
+        n = pl.size // L - 1
+        if pl.ndim != 1 or pl.size != (n + 1) * L or n < 0:
+            raise ValueError("pcm_left must be int16 [(n_frames + 1) * %d]" % L)
+        joint = pcm_right is not None
+        pr = None
+        if joint:
+            pr = np.ascontiguousarray(pcm_right, dtype=np.int16)
+            if pr.shape != pl.shape:
+                raise ValueError("pcm_right must match pcm_left")
+        nb = len(self.bands(L, L))
+        ns, nsig = (2, 4) if joint else (1, 1)
+        want = dict(overall_scale=((n, nsig), np.int32), scale_factor=((n, ns, nb), np.int32),
+                    bit_alloc=((n, ns, nb), np.int32), mantissa=((n, ns, L), np.uint16), reservoir_out=((n,), np.int32))
+        if joint:
+            want["ms_switch"] = ((n, nb), np.int32)
+        res = {}
+        for k, (shape, dt) in want.items():
+            arr = None if out is None else out.get(k)
+            if arr is None:
+                arr = np.empty(shape, dt)
+            elif arr.shape != shape or arr.dtype != dt or not arr.flags.c_contiguous:
+                raise ValueError("out[%r] must be a C-contiguous %s array of shape %s" % (k, np.dtype(dt).name, shape))
+            res[k] = arr
+        res_in = _reservoir(reservoir_in, n)
+        vp = lambda arr: None if arr is None else arr.ctypes.data_as(C.c_void_p)
+        self._check(lib.mrc_encode_stream_pcm16(self._h, n, vp(pl), vp(pr), vp(res_in), vp(res["overall_scale"]),
+                                                vp(res.get("ms_switch")), vp(res["scale_factor"]), vp(res["bit_alloc"]),
+                                                vp(res["mantissa"]), vp(res["reservoir_out"]), int(chunk_frames)))
+        return res
+
+    def pcm_to_float(self, pcm):
+        pcm = np.ascontiguousarray(pcm, dtype=np.int16)
+        out = np.empty(pcm.shape, np.float64)
+        self._check(lib.mrc_pcm_to_float(self._h, pcm.size, pcm.ctypes.data_as(C.c_void_p), _p(out, _f64p)))
+        return out
+
+    def quantize_uniform(self, x, n_bits):
+        x = _f64(np.atleast_1d(x))
+        out = np.empty(x.shape, np.int64)
+        self._check(lib.mrc_quantize_uniform(self._h, x.size, int(n_bits), _p(x, _f64p), _p(out, _i64p)))
+        return out
+
+    def bark(self, f):
+        f = _f64(np.atleast_1d(f))
+        out = np.empty(f.shape, np.float64)
+        self._check(lib.mrc_bark(self._h, f.size, _p(f, _f64p), _p(out, _f64p)))
         return out
 
     def window(self, blocks, a, b):
@@ -255,13 +368,20 @@ class Handle:
                                 _p(thr, _f64p)))
         return (smr, thr) if want_thresh else smr
 
-    def bitalloc(self, budget, max_mant_bits, n_lines, smr):
+    def bitalloc(self, budget, max_mant_bits, n_lines, smr, want_smr_after=False):
+        """-> (bits [n][nb], bits_left [n]) and, with want_smr_after, the running SMRs the loop leaves behind
+        (bitalloc.py:132-151 updates its SMR argument in place)."""
         smr = _f64(np.atleast_2d(smr))
         n, nb = smr.shape
         budget = _f64(np.broadcast_to(np.asarray(budget, dtype=np.float64), (n,)))
         nl = _i32(n_lines)
         bits = np.empty((n, nb), np.int32)
         left = np.empty(n, np.int32)
+        if want_smr_after:
+            after = smr.copy()
+            self._check(lib.mrc_bitalloc_inplace(self._h, n, nb, int(max_mant_bits), _p(nl, _i32p), _p(budget, _f64p),
+                                                 _p(after, _f64p), _p(bits, _i32p), _p(left, _i32p)))
+            return bits, left, after
         self._check(lib.mrc_bitalloc(self._h, n, nb, int(max_mant_bits), _p(nl, _i32p), _p(budget, _f64p),
                                      _p(smr, _f64p), _p(bits, _i32p), _p(left, _i32p)))
         return bits, left
@@ -373,6 +493,13 @@ class Handle:
                                        reservoir_in, overall_scale, ms_switch, bit_alloc, scale_factor, mantissa,
                                        reservoir_out, lines_out, stream))
 
+    def dev_encode_ex(self, a, b, n_frames, ch_left, ch_right, sample_format, frame_stride, offsets, reservoir_in,
+                      overall_scale, ms_switch, bit_alloc, scale_factor, mantissa, mantissa_format, reservoir_out,
+                      lines_out=None, stream=None):
+        self._check(lib.mrc_dev_encode_ex(self._h, a, b, n_frames, ch_left, ch_right, int(sample_format), frame_stride,
+                                          offsets, reservoir_in, overall_scale, ms_switch, bit_alloc, scale_factor,
+                                          mantissa, int(mantissa_format), reservoir_out, lines_out, stream))
+
     def dev_mdct(self, a, b, n_frames, ch_left, ch_right, frame_stride, offsets, lines, overall_scale, stream=None):
         self._check(lib.mrc_dev_mdct(self._h, a, b, n_frames, ch_left, ch_right, frame_stride, offsets, lines,
                                      overall_scale, stream))
@@ -398,3 +525,40 @@ class Handle:
         ms = np.zeros(3, np.float64)
         self._check(lib.mrc_get_stage_ms(self._h, _p(ms, _f64p)))
         return ms
+
+    def kernel_ms(self):
+        """device time of the last timed encode per kernel: MDCT, smr, band_stats (joint), bitalloc, quantize"""
+        ms = np.zeros(5, np.float64)
+        self._check(lib.mrc_get_kernel_ms(self._h, _p(ms, _f64p)))
+        return ms
+
+
+MRC_SAMPLES_F64, MRC_SAMPLES_PCM16 = 0, 1
+MRC_MANTISSA_I32, MRC_MANTISSA_I16 = 0, 1
+
+
+class PinnedArray:
+    """A NumPy array over page-locked host memory (mrc_host_alloc): what makes the copies of
+    Handle.encode_stream_pcm16 asynchronous.  Keep the object alive as long as `.array` is used."""
+
+    def __init__(self, shape, dtype):
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        self._p = C.c_void_p()
+        rc = lib.mrc_host_alloc(C.byref(self._p), max(n, 1))
+        if rc != 0:
+            raise MrcError("mrc_host_alloc(%d bytes) failed (%d)" % (n, rc))
+        buf = (C.c_char * max(n, 1)).from_address(self._p.value)
+        self.array = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+    def free(self):
+        if getattr(self, "_p", None) is not None and self._p.value:
+            self.array = None
+            lib.mrc_host_free(self._p)
+            self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

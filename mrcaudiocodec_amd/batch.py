@@ -24,48 +24,53 @@ class StreamEncoder:
         self.device = torch.device("cuda", self.h.cfg.device_id)
         self._out = {}
 
-    def _alloc(self, n, joint, nb, half):
+    def _alloc(self, n, joint, nb, half, mant16=False):
         nsig, nstream = (4, 2) if joint else (1, 1)
         i32 = dict(dtype=torch.int32, device=self.device)
         return dict(overall_scale=torch.empty((n, nsig), **i32),
                     ms_switch=torch.empty((n, nb), **i32) if joint else None,
                     bit_alloc=torch.empty((n, nstream, nb), **i32),
                     scale_factor=torch.empty((n, nstream, nb), **i32),
-                    mantissa=torch.empty((n, nstream, half), **i32),
+                    # uint16 codes travel as int16 storage (torch has no general uint16): view as uint16 on the host
+                    mantissa=torch.empty((n, nstream, half), dtype=torch.int16 if mant16 else torch.int32, device=self.device),
                     reservoir_out=torch.empty((n,), **i32))
 
-    def _outputs(self, n, joint, nb, half):
-        key = (n, joint, nb, half)
+    def _outputs(self, n, joint, nb, half, mant16=False):
+        key = (n, joint, nb, half, mant16)
         if key not in self._out:
-            self._out = {key: self._alloc(n, joint, nb, half)}
+            if len(self._out) >= 8:                           # a block-switched stream cycles through four shapes
+                self._out.clear()
+            self._out[key] = self._alloc(n, joint, nb, half, mant16)
         return self._out[key]
 
     def encode(self, a, b, left, right, n_frames, frame_stride, offsets=None, reservoir_in=None, lines_out=None,
-               fresh=False, offsets_checked=False):
-        """Encode n_frames blocks of shape (a,b) read from device tensor(s) `left` (and `right` for joint stereo).
-        Returns a dict of device tensors (reused between calls of the same size unless fresh=True)."""
+               fresh=False, offsets_checked=False, mantissa16=False):
+        """Encode n_frames blocks of shape (a,b) read from device tensor(s) `left` (and `right` for joint stereo):
+        float64 signed fractions or int16 PCM codes (converted on load as pcmfile.py:91-100 does).  mantissa16: the
+        mantissa plane as 16-bit codes (int16 storage of uint16 values).  Returns a dict of device tensors (reused
+        between calls of the same size unless fresh=True)."""
         for t in (left, right, offsets, reservoir_in, lines_out):
             if t is not None and (not t.is_cuda or not t.is_contiguous()):
                 raise ValueError("device-contiguous tensors expected")
-        if left.dtype != torch.float64 or (right is not None and right.dtype != torch.float64):
-            raise ValueError("PCM must be float64 signed fractions")
+        if left.dtype not in (torch.float64, torch.int16) or (right is not None and right.dtype != left.dtype):
+            raise ValueError("PCM must be float64 signed fractions or int16 codes (both channels alike)")
         if not (offsets is not None and offsets_checked):    # (reading offsets back synchronises with the device)
             last = (offsets.max().item() if offsets is not None else (n_frames - 1) * frame_stride) + a + b
             if n_frames > 0 and (left.numel() < last or (right is not None and right.numel() < last)):
                 raise ValueError("stream too short for %d frames" % n_frames)
         nb = len(self.h.bands(a, b))
-        out = (self._alloc if fresh else self._outputs)(n_frames, right is not None, nb, (a + b) // 2)
+        out = (self._alloc if fresh else self._outputs)(n_frames, right is not None, nb, (a + b) // 2, mantissa16)
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        self.h.dev_encode(a, b, n_frames, _ptr(left), _ptr(right), frame_stride, _ptr(offsets), _ptr(reservoir_in),
-                          _ptr(out["overall_scale"]), _ptr(out["ms_switch"]), _ptr(out["bit_alloc"]),
-                          _ptr(out["scale_factor"]), _ptr(out["mantissa"]), _ptr(out["reservoir_out"]),
-                          _ptr(lines_out), stream)
+        self.h.dev_encode_ex(a, b, n_frames, _ptr(left), _ptr(right), 1 if left.dtype == torch.int16 else 0, frame_stride,
+                             _ptr(offsets), _ptr(reservoir_in), _ptr(out["overall_scale"]), _ptr(out["ms_switch"]),
+                             _ptr(out["bit_alloc"]), _ptr(out["scale_factor"]), _ptr(out["mantissa"]),
+                             1 if mantissa16 else 0, _ptr(out["reservoir_out"]), _ptr(lines_out), stream)
         return {k: v for k, v in out.items() if v is not None}
 
-    def encode_long(self, left, right, n_frames, reservoir_in=None):
+    def encode_long(self, left, right, n_frames, reservoir_in=None, mantissa16=False):
         """All-long-block stream (a = b = nMDCTLines), hop-overlapped layout."""
         L = self.h.cfg.n_mdct_lines
-        return self.encode(L, L, left, right, n_frames, L, None, reservoir_in)
+        return self.encode(L, L, left, right, n_frames, L, None, reservoir_in, mantissa16=mantissa16)
 
     def huffman_gain(self, a, b, out, use_huffman=True):
         """Prices the Huffman tables for the blocks in `out` (a dict from encode) on the device and returns

@@ -11,15 +11,15 @@ Kept from the reference:
   JointEncodeChannels(dataLeft, dataRight, cp)   codecThem.py:359-574
   Encode / EncodeNoHuff / JointEncode            codecThem.py:205-278
   calculateHuffmanGain(mantissa, bitAlloc, cp)   codecThem.py:136-203  (host side, as BASELINE.json's north_star says)
-  L1 names re-exported by codecThem.py:14-21:    TransitionWindow, KBDWindow, MDCT, CalcSMRs,
-      getMaskedThreshold, BitAlloc, ScaleFactor, vMantissa, MSSwitchSFBands, StereoMaskingFactor, OverallSMRs --
-      each runs on the GPU.
+  Decode / JointDecode                           codecThem.py:30-134   (the decoder core; "next" row f-4)
+  L1 names re-exported by codecThem.py:14-21:    TransitionWindow, KBDWindow, MDCT, CalcSMRs, getMaskedThreshold, Bark,
+      BitAlloc, ScaleFactor, QuantizeUniform, vQuantizeUniform, Mantissa, vMantissa, MSSwitchSFBands,
+      StereoMaskingFactor, OverallSMRs -- each runs on the GPU (OverallSMRs is a per-band select on the host).
 codingParams is the reference's attribute bag (audiofile.py:51-53): read a, b, nMDCTLines, nScaleBits,
 nMantSizeBits, targetBitsPerSample, sampleRate, sfBands, blkswBitA/B, nChannels, bitReservoir;
 written bitReservoir (codecThem.py:224,274,332,503).
 Differences, all documented in DESIGN.md: Huffman table ids follow sorted table names instead of
-directory order; tables come from package data, not ./training_data/*.pkl; Decode/JointDecode are not
-provided (decode is out of scope).  There is no CPU fallback.
+directory order; tables come from package data, not ./training_data/*.pkl.  There is no CPU fallback.
 """
 import os
 
@@ -252,9 +252,13 @@ def getMaskedThreshold(data, MDCTdata, MDCTscale, sampleRate, sfBands):
 
 
 def BitAlloc(bitBudget, maxMantBits, nBands, nLines, SMR):
-    """bitalloc.py:106-155 -> (bits float64[nBands], int(bitsLeft)).  SMR is not modified."""
-    bits, left = _default_handle().bitalloc(float(bitBudget), int(maxMantBits), np.asarray(nLines)[:nBands],
-                                            np.asarray(SMR, dtype=np.float64)[:nBands])
+    """bitalloc.py:106-155 -> (bits float64[nBands], int(bitsLeft)).  Like the reference, a float64 NumPy SMR array is
+    UPDATED IN PLACE (bitalloc.py:132-151): -12 for a band's first grant (2 bits), -6 for every further bit,
+    -99999999999999999.0 once the band is retired -- the running values come back from the kernel."""
+    bits, left, after = _default_handle().bitalloc(float(bitBudget), int(maxMantBits), np.asarray(nLines)[:nBands],
+                                                   np.asarray(SMR, dtype=np.float64)[:nBands], want_smr_after=True)
+    if isinstance(SMR, np.ndarray) and SMR.dtype == np.float64:
+        SMR[:nBands] = after[0]
     return (bits[0].astype(np.float64), int(left[0]))
 
 
@@ -266,6 +270,27 @@ def ScaleFactor(aNum, nScaleBits=3, nMantBits=5):
 def vMantissa(aNumVec, scale, nScaleBits=3, nMantBits=5):
     """quantize.py:294-322 (float64 integer-valued result, like the reference)."""
     return _default_handle().mantissa(aNumVec, int(scale), nScaleBits, int(nMantBits)).astype(np.float64)
+
+
+def Mantissa(aNum, scale, nScaleBits=3, nMantBits=5):
+    """quantize.py:222-249: the scalar form."""
+    return int(_default_handle().mantissa([float(aNum)], int(scale), nScaleBits, int(nMantBits))[0])
+
+
+def vQuantizeUniform(aNumVec, nBits):
+    """quantize.py:61-87 (float64 integer-valued result, like the reference)."""
+    return _default_handle().quantize_uniform(np.asarray(aNumVec, dtype=np.float64), int(nBits)).astype(np.float64)
+
+
+def QuantizeUniform(aNum, nBits):
+    """quantize.py:12-38: the scalar form."""
+    return int(_default_handle().quantize_uniform([float(aNum)], int(nBits))[0])
+
+
+def Bark(f):
+    """psychoac.py:27-29 (imported by codecThem.py:20)."""
+    z = _default_handle().bark(np.asarray(f, dtype=np.float64))
+    return z if np.ndim(f) else float(z[0])
 
 
 def MSSwitchSFBands(mdct_left, mdct_right, sfBands):

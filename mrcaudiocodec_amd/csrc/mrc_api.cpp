@@ -34,20 +34,43 @@ struct DevBuf {
 
 }  // namespace
 
+// intermediate results of one encode call (lines, SMRs, band peaks); one set per stream that encodes concurrently
+struct Workspace {
+    DevBuf lines, smr, peak;
+    void release() { lines.release(); smr.release(); peak.release(); }
+};
+
+// one lane of the pipelined host entry points: a stream with its own inputs, workspace and outputs, so that the
+// H2D copy of chunk i+1 and the D2H copy of chunk i-1 run beside the kernels of chunk i
+struct Lane {
+    hipStream_t st = nullptr;
+    Workspace ws;
+    DevBuf pcmL, pcmR, resIn, oScale, ms, ba, sf, mant, resOut;
+    void release() {
+        ws.release();
+        for (DevBuf* b : {&pcmL, &pcmR, &resIn, &oScale, &ms, &ba, &sf, &mant, &resOut}) b->release();
+        if (st) (void)hipStreamDestroy(st);
+        st = nullptr;
+    }
+};
+constexpr int kLanes = 3;
+constexpr int kKernelEvents = 6;     // boundaries of: mdct | smr | band_stats | bitalloc | quantize
+
 struct mrc_handle {
     mrc_config cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
     std::map<std::pair<int, int>, HostShape> shapes;
     std::string error;
-    // workspace of mrc_dev_encode
-    DevBuf wsLines, wsScale, wsSmr, wsPeak;
+    Workspace ws;                    // workspace of mrc_dev_encode* (calls on one handle are serialised)
+    Lane lanes[kLanes];              // mrc_encode_stream_pcm16
     // staging of the host entry points
     DevBuf inL, inR, inAux, inAux2, inAux3, outA, outB, outC, outD, outE, outF, outG;
     bool timing = false;
     bool exactSpread = false;        // mrc_set_option(MRC_OPT_EXACT_SPREAD)
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[kKernelEvents] = {};
     double stageMs[3] = {0, 0, 0};
+    double kernelMs[5] = {0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -68,12 +91,14 @@ int hip_fail(mrc_handle* h, hipError_t e, const char* what) {
     } while (0)
 
 int get_shape(mrc_handle* h, int a, int b, const HostShape** out) {
+    // every entry point that launches comes through here first: the launches, the tables and the caller's pointers
+    // all belong to the handle's device, whatever the calling thread's current device was
+    MRC_HIP(h, hipSetDevice(h->device));
     auto key = std::make_pair(a, b);
     auto it = h->shapes.find(key);
     if (it == h->shapes.end()) {
         HostShape hs;
         std::string err;
-        MRC_HIP(h, hipSetDevice(h->device));
         if (!build_shape(h->cfg, a, b, &hs, &err)) return fail(h, MRC_ERR_INVALID, err);
         it = h->shapes.emplace(key, std::move(hs)).first;
     }
@@ -150,7 +175,12 @@ void mrc_destroy(mrc_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& kv : h->shapes) free_shape(&kv.second);
-    for (DevBuf* b : {&h->wsLines, &h->wsScale, &h->wsSmr, &h->wsPeak, &h->inL, &h->inR, &h->inAux, &h->inAux2, &h->inAux3,
+    for (auto& lane : h->lanes) {
+        if (lane.st) (void)hipStreamSynchronize(lane.st);
+        lane.release();
+    }
+    h->ws.release();
+    for (DevBuf* b : {&h->inL, &h->inR, &h->inAux, &h->inAux2, &h->inAux3,
                       &h->outA, &h->outB, &h->outC, &h->outD, &h->outE, &h->outF, &h->outG})
         b->release();
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
@@ -201,6 +231,12 @@ int mrc_get_stage_ms(mrc_handle* h, double* ms) {
     return MRC_OK;
 }
 
+int mrc_get_kernel_ms(mrc_handle* h, double* ms) {
+    if (!h || !ms) return MRC_ERR_INVALID;
+    for (int i = 0; i < 5; ++i) ms[i] = h->kernelMs[i];
+    return MRC_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- device API
 
 int mrc_dev_mdct(mrc_handle* h, int a, int b, int64_t n_frames, const double* ch_left, const double* ch_right,
@@ -210,8 +246,8 @@ int mrc_dev_mdct(mrc_handle* h, int a, int b, int64_t n_frames, const double* ch
     const HostShape* hs;
     int rc = get_shape(h, a, b, &hs);
     if (rc) return rc;
-    MRC_HIP(h, launch_mdct(hs->dev, n_frames, ch_left, ch_right, frame_stride, offsets, true, lines, overall_scale,
-                           pick_stream(h, stream)));
+    MRC_HIP(h, launch_mdct(hs->dev, n_frames, ch_left, ch_right, kSampleF64, frame_stride, offsets, true, lines,
+                           overall_scale, pick_stream(h, stream)));
     return MRC_OK;
 }
 
@@ -223,8 +259,8 @@ int mrc_dev_smr(mrc_handle* h, int a, int b, int64_t n_frames, const double* ch_
     const HostShape* hs;
     int rc = get_shape(h, a, b, &hs);
     if (rc) return rc;
-    MRC_HIP(h, launch_smr(hs->dev, n_frames, ch_left, ch_right, frame_stride, offsets, lines, overall_scale, smr,
-                          thresh, nullptr, h->exactSpread, pick_stream(h, stream)));
+    MRC_HIP(h, launch_smr(hs->dev, n_frames, ch_left, ch_right, kSampleF64, frame_stride, offsets, lines, overall_scale,
+                          smr, thresh, nullptr, h->exactSpread, pick_stream(h, stream)));
     return MRC_OK;
 }
 
@@ -238,11 +274,10 @@ int mrc_dev_alloc_quant(mrc_handle* h, int a, int b, int64_t n_frames, int joint
     const HostShape* hs;
     int rc = get_shape(h, a, b, &hs);
     if (rc) return rc;
-    MRC_HIP(h, hipSetDevice(h->device));
-    MRC_HIP(h, h->wsPeak.reserve(alloc_workspace_bytes(hs->dev, n_frames, joint)));
+    MRC_HIP(h, h->ws.peak.reserve(alloc_workspace_bytes(hs->dev, n_frames, joint)));
     MRC_HIP(h, launch_alloc_quant(hs->dev, n_frames, joint, lines, overall_scale, smr, reservoir_in, ms_switch,
-                                  bit_alloc, scale_factor, mantissa, reservoir_out, h->wsPeak.as<double>(), false,
-                                  pick_stream(h, stream)));
+                                  bit_alloc, scale_factor, mantissa, MRC_MANTISSA_I32, reservoir_out,
+                                  h->ws.peak.as<double>(), false, nullptr, pick_stream(h, stream)));
     return MRC_OK;
 }
 
@@ -262,6 +297,7 @@ int mrc_dev_decode(mrc_handle* h, int a, int b, int64_t n_blocks, int n_streams,
 
 int mrc_dev_pcm16(mrc_handle* h, int64_t n, const double* x, int16_t* out, void* stream) {
     if (!h || n < 0 || !x || !out) return fail(h, MRC_ERR_INVALID, "mrc_dev_pcm16: bad argument");
+    MRC_HIP(h, hipSetDevice(h->device));
     MRC_HIP(h, launch_pcm16(n, x, out, pick_stream(h, stream)));
     return MRC_OK;
 }
@@ -280,47 +316,79 @@ int mrc_dev_huffman_gain(mrc_handle* h, int a, int b, int64_t n_frames, int n_st
     return MRC_OK;
 }
 
-int mrc_dev_encode(mrc_handle* h, int a, int b, int64_t n_frames, const double* ch_left, const double* ch_right,
-                   int64_t frame_stride, const int64_t* offsets, const int32_t* reservoir_in,
-                   int32_t* overall_scale, int32_t* ms_switch, int32_t* bit_alloc, int32_t* scale_factor,
-                   int32_t* mantissa, int32_t* reservoir_out, double* lines_out, void* stream) {
+}  // extern "C"
+
+namespace {
+
+// The whole per-block path for n blocks of one shape, queued on `st`: windowed MDCT + overall scale -> SMRs (and
+// per-band peaks) -> [M/S switch] -> bit allocation -> scale factors + mantissas.  Inputs and outputs are device
+// pointers; `ws` holds the intermediate results and must not be shared with a call running on another stream.
+int encode_core(mrc_handle* h, const DevShape& S, int64_t n, const void* chL, const void* chR, int fmt, int64_t stride,
+                const int64_t* offsets, const int32_t* resIn, int32_t* oscale, int32_t* msSwitch, int32_t* bitAlloc,
+                int32_t* scaleFactor, void* mantissa, int mantFmt, int32_t* resOut, double* linesOut, Workspace& ws,
+                hipStream_t st) {
+    const int joint = chR ? 1 : 0;
+    const int nsig = joint ? 4 : 1;
+    double* lines = linesOut;
+    if (!lines) {
+        MRC_HIP(h, ws.lines.reserve((size_t)n * nsig * S.halfN * sizeof(double)));
+        lines = ws.lines.as<double>();
+    }
+    MRC_HIP(h, ws.smr.reserve((size_t)n * nsig * S.nBands * sizeof(double)));
+    MRC_HIP(h, ws.peak.reserve(alloc_workspace_bytes(S, n, joint)));
+    double* smr = ws.smr.as<double>();
+    const bool timing = h->timing;
+    if (timing) MRC_HIP(h, hipEventRecord(h->ev[0], st));
+    MRC_HIP(h, launch_mdct(S, n, chL, chR, fmt, stride, offsets, true, lines, oscale, st));
+    if (timing) MRC_HIP(h, hipEventRecord(h->ev[1], st));
+    MRC_HIP(h, launch_smr(S, n, chL, chR, fmt, stride, offsets, lines, oscale, smr, nullptr, ws.peak.as<double>(),
+                          h->exactSpread, st));
+    if (timing) MRC_HIP(h, hipEventRecord(h->ev[2], st));
+    MRC_HIP(h, launch_alloc_quant(S, n, joint, lines, oscale, smr, resIn, msSwitch, bitAlloc, scaleFactor, mantissa,
+                                  mantFmt, resOut, ws.peak.as<double>(), true, timing ? &h->ev[3] : nullptr, st));
+    if (timing) {
+        MRC_HIP(h, hipEventRecord(h->ev[5], st));
+        MRC_HIP(h, hipEventSynchronize(h->ev[5]));
+        for (int i = 0; i < 5; ++i) {
+            float ms = 0.f;
+            MRC_HIP(h, hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+            h->kernelMs[i] = ms;
+        }
+        h->stageMs[0] = h->kernelMs[0];
+        h->stageMs[1] = h->kernelMs[1];
+        h->stageMs[2] = h->kernelMs[2] + h->kernelMs[3] + h->kernelMs[4];
+    }
+    return MRC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mrc_dev_encode_ex(mrc_handle* h, int a, int b, int64_t n_frames, const void* ch_left, const void* ch_right,
+                      int sample_format, int64_t frame_stride, const int64_t* offsets, const int32_t* reservoir_in,
+                      int32_t* overall_scale, int32_t* ms_switch, int32_t* bit_alloc, int32_t* scale_factor,
+                      void* mantissa, int mantissa_format, int32_t* reservoir_out, double* lines_out, void* stream) {
     if (!h || !ch_left || !overall_scale || !bit_alloc || !scale_factor || !mantissa || !reservoir_out ||
-        (ch_right && !ms_switch) || n_frames < 0)
+        (ch_right && !ms_switch) || n_frames < 0 ||
+        (sample_format != MRC_SAMPLES_F64 && sample_format != MRC_SAMPLES_PCM16) ||
+        (mantissa_format != MRC_MANTISSA_I32 && mantissa_format != MRC_MANTISSA_I16))
         return fail(h, MRC_ERR_INVALID, "mrc_dev_encode: bad argument");
     const HostShape* hs;
     int rc = get_shape(h, a, b, &hs);
     if (rc) return rc;
-    const DevShape& S = hs->dev;
-    const int joint = ch_right ? 1 : 0;
-    const int nsig = joint ? 4 : 1;
-    hipStream_t st = pick_stream(h, stream);
-    MRC_HIP(h, hipSetDevice(h->device));
-    double* lines = lines_out;
-    if (!lines) {
-        MRC_HIP(h, h->wsLines.reserve((size_t)n_frames * nsig * S.halfN * sizeof(double)));
-        lines = h->wsLines.as<double>();
-    }
-    MRC_HIP(h, h->wsSmr.reserve((size_t)n_frames * nsig * S.nBands * sizeof(double)));
-    MRC_HIP(h, h->wsPeak.reserve(alloc_workspace_bytes(S, n_frames, joint)));
-    double* smr = h->wsSmr.as<double>();
-    if (h->timing) MRC_HIP(h, hipEventRecord(h->ev[0], st));
-    MRC_HIP(h, launch_mdct(S, n_frames, ch_left, ch_right, frame_stride, offsets, true, lines, overall_scale, st));
-    if (h->timing) MRC_HIP(h, hipEventRecord(h->ev[1], st));
-    MRC_HIP(h, launch_smr(S, n_frames, ch_left, ch_right, frame_stride, offsets, lines, overall_scale, smr, nullptr,
-                          h->wsPeak.as<double>(), h->exactSpread, st));
-    if (h->timing) MRC_HIP(h, hipEventRecord(h->ev[2], st));
-    MRC_HIP(h, launch_alloc_quant(S, n_frames, joint, lines, overall_scale, smr, reservoir_in, ms_switch, bit_alloc,
-                                  scale_factor, mantissa, reservoir_out, h->wsPeak.as<double>(), true, st));
-    if (h->timing) {
-        MRC_HIP(h, hipEventRecord(h->ev[3], st));
-        MRC_HIP(h, hipEventSynchronize(h->ev[3]));
-        for (int i = 0; i < 3; ++i) {
-            float ms = 0.f;
-            MRC_HIP(h, hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
-            h->stageMs[i] = ms;
-        }
-    }
-    return MRC_OK;
+    return encode_core(h, hs->dev, n_frames, ch_left, ch_right, sample_format, frame_stride, offsets, reservoir_in,
+                       overall_scale, ms_switch, bit_alloc, scale_factor, mantissa, mantissa_format, reservoir_out,
+                       lines_out, h->ws, pick_stream(h, stream));
+}
+
+int mrc_dev_encode(mrc_handle* h, int a, int b, int64_t n_frames, const double* ch_left, const double* ch_right,
+                   int64_t frame_stride, const int64_t* offsets, const int32_t* reservoir_in,
+                   int32_t* overall_scale, int32_t* ms_switch, int32_t* bit_alloc, int32_t* scale_factor,
+                   int32_t* mantissa, int32_t* reservoir_out, double* lines_out, void* stream) {
+    return mrc_dev_encode_ex(h, a, b, n_frames, ch_left, ch_right, MRC_SAMPLES_F64, frame_stride, offsets, reservoir_in,
+                             overall_scale, ms_switch, bit_alloc, scale_factor, mantissa, MRC_MANTISSA_I32,
+                             reservoir_out, lines_out, stream);
 }
 
 // ---------------------------------------------------------------------------------------------- host API
@@ -330,6 +398,10 @@ namespace {
 struct Staged {
     mrc_handle* h;
     hipStream_t st;
+    // Every host entry point owns one Staged: whichever way the function is left (also through an error return in
+    // the middle), the stream is drained before the caller's buffers -- and any host temporaries declared BEFORE the
+    // Staged object -- go out of scope under a copy that is still in flight.
+    ~Staged() { if (st) (void)hipStreamSynchronize(st); }
     int up(DevBuf& buf, const void* src, size_t bytes) {
         MRC_HIP(h, buf.reserve(bytes ? bytes : 1));
         if (bytes) MRC_HIP(h, hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, st));
@@ -402,6 +474,236 @@ int mrc_encode_joint(mrc_handle* h, int64_t n_blocks, int a, int b, const double
                        mantissa, reservoir_out, mdct_out);
 }
 
+// ---- pinned host memory: what makes the copies of mrc_encode_stream_pcm16 asynchronous --------------------------
+int mrc_host_alloc(void** out, size_t bytes) {
+    if (!out) return MRC_ERR_INVALID;
+    *out = nullptr;
+    return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? MRC_OK : MRC_ERR_NOMEM;
+}
+int mrc_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? MRC_OK : MRC_ERR_HIP; }
+int mrc_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return MRC_ERR_INVALID;
+    return hipHostRegister(p, bytes, hipHostRegisterDefault) == hipSuccess ? MRC_OK : MRC_ERR_HIP;
+}
+int mrc_host_unregister(void* p) { return (!p || hipHostUnregister(p) == hipSuccess) ? MRC_OK : MRC_ERR_HIP; }
+
+// ---- 16-bit PCM in host memory -> codes in host memory, pipelined ---------------------------------------------
+int mrc_encode_stream_pcm16(mrc_handle* h, int64_t n_frames, const int16_t* pcm_left, const int16_t* pcm_right,
+                            const int32_t* reservoir_in, int32_t* overall_scale, int32_t* ms_switch,
+                            int32_t* scale_factor, int32_t* bit_alloc, uint16_t* mantissa16, int32_t* reservoir_out,
+                            int64_t chunk_frames) {
+    if (!h || !pcm_left || !overall_scale || !scale_factor || !bit_alloc || !mantissa16 || !reservoir_out ||
+        (pcm_right && !ms_switch) || n_frames < 0 || chunk_frames < 0)
+        return fail(h, MRC_ERR_INVALID, "mrc_encode_stream_pcm16: bad argument");
+    if (n_frames == 0) return MRC_OK;
+    const int L = h->cfg.n_mdct_lines;
+    const HostShape* hs;
+    MRC_TRY(get_shape(h, L, L, &hs));
+    const DevShape& S = hs->dev;
+    const int joint = pcm_right ? 1 : 0, nsig = joint ? 4 : 1, nstream = joint ? 2 : 1;
+    int64_t chunk = chunk_frames ? chunk_frames : 16384;
+    if (chunk > n_frames) chunk = n_frames;
+    // lanes: created on first use, buffers sized for one chunk (+ the one-hop halo in front of it)
+    const size_t szPcm = (size_t)(chunk + 1) * L * sizeof(int16_t);
+    for (auto& lane : h->lanes) {
+        if (!lane.st) MRC_HIP(h, hipStreamCreateWithFlags(&lane.st, hipStreamNonBlocking));
+        MRC_HIP(h, lane.pcmL.reserve(szPcm));
+        if (joint) MRC_HIP(h, lane.pcmR.reserve(szPcm));
+        MRC_HIP(h, lane.resIn.reserve((size_t)chunk * sizeof(int32_t)));
+        MRC_HIP(h, lane.oScale.reserve((size_t)chunk * nsig * sizeof(int32_t)));
+        MRC_HIP(h, lane.ms.reserve((size_t)chunk * S.nBands * sizeof(int32_t)));
+        MRC_HIP(h, lane.ba.reserve((size_t)chunk * nstream * S.nBands * sizeof(int32_t)));
+        MRC_HIP(h, lane.sf.reserve((size_t)chunk * nstream * S.nBands * sizeof(int32_t)));
+        MRC_HIP(h, lane.mant.reserve((size_t)chunk * nstream * S.halfN * sizeof(uint16_t)));
+        MRC_HIP(h, lane.resOut.reserve((size_t)chunk * sizeof(int32_t)));
+        MRC_HIP(h, lane.ws.lines.reserve((size_t)chunk * nsig * S.halfN * sizeof(double)));
+        MRC_HIP(h, lane.ws.smr.reserve((size_t)chunk * nsig * S.nBands * sizeof(double)));
+        MRC_HIP(h, lane.ws.peak.reserve(alloc_workspace_bytes(S, chunk, joint)));
+    }
+    struct DrainAll {                       // whichever way we leave: nothing of ours is still using the caller's memory
+        mrc_handle* h;
+        ~DrainAll() { for (auto& lane : h->lanes) if (lane.st) (void)hipStreamSynchronize(lane.st); }
+    } drain{h};
+    const bool wasTiming = h->timing;
+    h->timing = false;                      // the per-kernel events of encode_core belong to ONE stream
+    int rc = MRC_OK;
+    int64_t c = 0;
+    for (int64_t f0 = 0; f0 < n_frames && rc == MRC_OK; f0 += chunk, ++c) {
+        Lane& lane = h->lanes[c % kLanes];
+        const int64_t n = (n_frames - f0 < chunk) ? n_frames - f0 : chunk;
+        hipStream_t st = lane.st;
+        // everything queued on lane.st is ordered behind the lane's previous chunk: its buffers are free again
+        const size_t inBytes = (size_t)(n + 1) * L * sizeof(int16_t);
+#define MRC_Q(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = hip_fail(h, e_, #call); break; } } while (0)
+        do {
+            MRC_Q(hipMemcpyAsync(lane.pcmL.p, pcm_left + f0 * L, inBytes, hipMemcpyHostToDevice, st));
+            if (joint) MRC_Q(hipMemcpyAsync(lane.pcmR.p, pcm_right + f0 * L, inBytes, hipMemcpyHostToDevice, st));
+            if (reservoir_in)
+                MRC_Q(hipMemcpyAsync(lane.resIn.p, reservoir_in + f0, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+            rc = encode_core(h, S, n, lane.pcmL.p, joint ? lane.pcmR.p : nullptr, kSampleI16, L, nullptr,
+                             reservoir_in ? lane.resIn.as<int32_t>() : nullptr, lane.oScale.as<int32_t>(),
+                             lane.ms.as<int32_t>(), lane.ba.as<int32_t>(), lane.sf.as<int32_t>(), lane.mant.p,
+                             MRC_MANTISSA_I16, lane.resOut.as<int32_t>(), nullptr, lane.ws, st);
+            if (rc != MRC_OK) break;
+            MRC_Q(hipMemcpyAsync(overall_scale + f0 * nsig, lane.oScale.p, (size_t)n * nsig * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            if (joint)
+                MRC_Q(hipMemcpyAsync(ms_switch + f0 * S.nBands, lane.ms.p, (size_t)n * S.nBands * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            MRC_Q(hipMemcpyAsync(bit_alloc + f0 * nstream * S.nBands, lane.ba.p, (size_t)n * nstream * S.nBands * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            MRC_Q(hipMemcpyAsync(scale_factor + f0 * nstream * S.nBands, lane.sf.p, (size_t)n * nstream * S.nBands * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            MRC_Q(hipMemcpyAsync(mantissa16 + f0 * nstream * S.halfN, lane.mant.p, (size_t)n * nstream * S.halfN * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
+            MRC_Q(hipMemcpyAsync(reservoir_out + f0, lane.resOut.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        } while (0);
+#undef MRC_Q
+    }
+    h->timing = wasTiming;
+    if (rc != MRC_OK) return rc;
+    for (auto& lane : h->lanes) MRC_HIP(h, hipStreamSynchronize(lane.st));
+    return MRC_OK;
+}
+
+// ---- blocks of MIXED shapes in one call (a block-switched stream): grouped by shape, one launch set per shape ------
+namespace {
+
+int encode_blocks_host(mrc_handle* h, int64_t n, const double* left, const double* right, const int32_t* a,
+                       const int32_t* b, const int32_t* reservoir_in, int32_t* overall_scale, int32_t* ms_switch,
+                       int32_t* scale_factor, int32_t* bit_alloc, int32_t* mantissa, int32_t* reservoir_out) {
+    if (!h || !left || !a || !b || !overall_scale || !scale_factor || !bit_alloc || !mantissa || !reservoir_out ||
+        (right && !ms_switch) || n < 0)
+        return fail(h, MRC_ERR_INVALID, "mrc_encode_blocks: bad argument");
+    if (n == 0) return MRC_OK;
+    MRC_HIP(h, hipSetDevice(h->device));
+    const int joint = right ? 1 : 0, nsig = joint ? 4 : 1, nstream = joint ? 2 : 1;
+    const int L = h->cfg.n_mdct_lines;
+    // where each block starts in the packed input, and which blocks share a shape
+    std::vector<int64_t> start((size_t)n + 1);
+    std::map<std::pair<int, int>, std::vector<int64_t>> groups;
+    start[0] = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        if (a[i] <= 0 || b[i] <= 0 || (a[i] + b[i]) / 2 > L)
+            return fail(h, MRC_ERR_INVALID, "mrc_encode_blocks: block shape out of range (a, b > 0, (a+b)/2 <= n_mdct_lines)");
+        start[(size_t)i + 1] = start[(size_t)i] + a[i] + b[i];
+        groups[std::make_pair((int)a[i], (int)b[i])].push_back(i);
+    }
+    std::vector<int64_t> offs;
+    std::vector<int32_t> resG, tScale, tSw, tSf, tBa, tMant, tRes;
+    Staged s{h, h->stream};                                 // (the vectors above outlive its drain)
+    const size_t inBytes = (size_t)start[(size_t)n] * sizeof(double);
+    MRC_TRY(s.up(h->inL, left, inBytes));
+    if (joint) MRC_TRY(s.up(h->inR, right, inBytes));
+    for (auto& kv : groups) {
+        const int ga = kv.first.first, gb = kv.first.second;
+        const std::vector<int64_t>& idx = kv.second;
+        const int64_t m = (int64_t)idx.size();
+        const HostShape* hs;
+        MRC_TRY(get_shape(h, ga, gb, &hs));
+        const DevShape& S = hs->dev;
+        offs.resize((size_t)m);
+        resG.assign((size_t)m, 0);
+        for (int64_t j = 0; j < m; ++j) {
+            offs[(size_t)j] = start[(size_t)idx[(size_t)j]];
+            if (reservoir_in) resG[(size_t)j] = reservoir_in[idx[(size_t)j]];
+        }
+        const size_t szScale = (size_t)m * nsig * sizeof(int32_t), szSw = (size_t)m * S.nBands * sizeof(int32_t);
+        const size_t szBand = (size_t)m * nstream * S.nBands * sizeof(int32_t);
+        const size_t szMant = (size_t)m * nstream * S.halfN * sizeof(int32_t), szRes = (size_t)m * sizeof(int32_t);
+        MRC_TRY(s.up(h->inAux, offs.data(), (size_t)m * sizeof(int64_t)));
+        MRC_TRY(s.up(h->inAux2, resG.data(), szRes));
+        MRC_HIP(h, h->outA.reserve(szScale)); MRC_HIP(h, h->outB.reserve(szSw)); MRC_HIP(h, h->outC.reserve(szBand));
+        MRC_HIP(h, h->outD.reserve(szBand));  MRC_HIP(h, h->outE.reserve(szMant)); MRC_HIP(h, h->outF.reserve(szRes));
+        MRC_TRY(encode_core(h, S, m, h->inL.p, joint ? h->inR.p : nullptr, kSampleF64, 0, h->inAux.as<int64_t>(),
+                            h->inAux2.as<int32_t>(), h->outA.as<int32_t>(), h->outB.as<int32_t>(), h->outD.as<int32_t>(),
+                            h->outC.as<int32_t>(), h->outE.p, MRC_MANTISSA_I32, h->outF.as<int32_t>(), nullptr, h->ws,
+                            h->stream));
+        tScale.resize((size_t)m * nsig); tSw.resize((size_t)m * S.nBands); tSf.resize((size_t)m * nstream * S.nBands);
+        tBa.resize((size_t)m * nstream * S.nBands); tMant.resize((size_t)m * nstream * S.halfN); tRes.resize((size_t)m);
+        MRC_TRY(s.down(tScale.data(), h->outA, szScale));
+        if (joint) MRC_TRY(s.down(tSw.data(), h->outB, szSw));
+        MRC_TRY(s.down(tSf.data(), h->outC, szBand));
+        MRC_TRY(s.down(tBa.data(), h->outD, szBand));
+        MRC_TRY(s.down(tMant.data(), h->outE, szMant));
+        MRC_TRY(s.down(tRes.data(), h->outF, szRes));
+        MRC_HIP(h, hipStreamSynchronize(h->stream));
+        // scatter into the caller's fixed-stride arrays (rows beyond the shape's band / line count are zeroed)
+        for (int64_t j = 0; j < m; ++j) {
+            const int64_t i = idx[(size_t)j];
+            for (int g = 0; g < nsig; ++g) overall_scale[i * nsig + g] = tScale[(size_t)(j * nsig + g)];
+            reservoir_out[i] = tRes[(size_t)j];
+            if (joint)
+                for (int k = 0; k < MRC_MAX_BANDS; ++k)
+                    ms_switch[i * MRC_MAX_BANDS + k] = k < S.nBands ? tSw[(size_t)(j * S.nBands + k)] : 0;
+            for (int c = 0; c < nstream; ++c) {
+                int32_t* sfRow = scale_factor + (i * nstream + c) * MRC_MAX_BANDS;
+                int32_t* baRow = bit_alloc + (i * nstream + c) * MRC_MAX_BANDS;
+                int32_t* mRow = mantissa + (i * nstream + c) * (int64_t)L;
+                for (int k = 0; k < MRC_MAX_BANDS; ++k) {
+                    sfRow[k] = k < S.nBands ? tSf[(size_t)((j * nstream + c) * S.nBands + k)] : 0;
+                    baRow[k] = k < S.nBands ? tBa[(size_t)((j * nstream + c) * S.nBands + k)] : 0;
+                }
+                std::memcpy(mRow, &tMant[(size_t)((j * nstream + c) * S.halfN)], (size_t)S.halfN * sizeof(int32_t));
+                std::memset(mRow + S.halfN, 0, (size_t)(L - S.halfN) * sizeof(int32_t));
+            }
+        }
+    }
+    return MRC_OK;
+}
+
+}  // namespace
+
+int mrc_encode_mono_blocks(mrc_handle* h, int64_t n_blocks, const double* blocks, const int32_t* a, const int32_t* b,
+                           const int32_t* reservoir_in, int32_t* overall_scale, int32_t* scale_factor,
+                           int32_t* bit_alloc, int32_t* mantissa, int32_t* reservoir_out) {
+    return encode_blocks_host(h, n_blocks, blocks, nullptr, a, b, reservoir_in, overall_scale, nullptr, scale_factor,
+                              bit_alloc, mantissa, reservoir_out);
+}
+
+int mrc_encode_joint_blocks(mrc_handle* h, int64_t n_blocks, const double* left, const double* right, const int32_t* a,
+                            const int32_t* b, const int32_t* reservoir_in, int32_t* overall_scale, int32_t* ms_switch,
+                            int32_t* scale_factor, int32_t* bit_alloc, int32_t* mantissa, int32_t* reservoir_out) {
+    if (!right || !ms_switch) return fail(h, MRC_ERR_INVALID, "mrc_encode_joint_blocks: null right channel or ms_switch");
+    return encode_blocks_host(h, n_blocks, left, right, a, b, reservoir_in, overall_scale, ms_switch, scale_factor,
+                              bit_alloc, mantissa, reservoir_out);
+}
+
+int mrc_quantize_uniform(mrc_handle* h, int64_t n, int n_bits, const double* x, int64_t* code) {
+    if (!h || n < 0 || !x || !code || n_bits < 1 || n_bits > 62)
+        return fail(h, MRC_ERR_INVALID, "mrc_quantize_uniform: bad argument (1 <= n_bits <= 62)");
+    if (n == 0) return MRC_OK;
+    MRC_HIP(h, hipSetDevice(h->device));
+    Staged s{h, h->stream};
+    MRC_TRY(s.up(h->inL, x, (size_t)n * sizeof(double)));
+    MRC_HIP(h, h->outG.reserve((size_t)n * sizeof(int64_t)));
+    MRC_HIP(h, launch_quantize_uniform(n, n_bits, h->inL.as<double>(), h->outG.as<long long>(), h->stream));
+    MRC_TRY(s.down(code, h->outG, (size_t)n * sizeof(int64_t)));
+    MRC_HIP(h, hipStreamSynchronize(h->stream));
+    return MRC_OK;
+}
+
+int mrc_bark(mrc_handle* h, int64_t n, const double* f, double* z) {
+    if (!h || n < 0 || !f || !z) return fail(h, MRC_ERR_INVALID, "mrc_bark: bad argument");
+    if (n == 0) return MRC_OK;
+    MRC_HIP(h, hipSetDevice(h->device));
+    Staged s{h, h->stream};
+    MRC_TRY(s.up(h->inL, f, (size_t)n * sizeof(double)));
+    MRC_HIP(h, h->outG.reserve((size_t)n * sizeof(double)));
+    MRC_HIP(h, launch_bark(n, h->inL.as<double>(), h->outG.as<double>(), h->stream));
+    MRC_TRY(s.down(z, h->outG, (size_t)n * sizeof(double)));
+    MRC_HIP(h, hipStreamSynchronize(h->stream));
+    return MRC_OK;
+}
+
+int mrc_pcm_to_float(mrc_handle* h, int64_t n, const int16_t* pcm, double* out) {
+    if (!h || n < 0 || !pcm || !out) return fail(h, MRC_ERR_INVALID, "mrc_pcm_to_float: bad argument");
+    if (n == 0) return MRC_OK;
+    MRC_HIP(h, hipSetDevice(h->device));
+    Staged s{h, h->stream};
+    MRC_TRY(s.up(h->inL, pcm, (size_t)n * sizeof(int16_t)));
+    MRC_HIP(h, h->outG.reserve((size_t)n * sizeof(double)));
+    MRC_HIP(h, launch_pcm_to_float(n, h->inL.as<short>(), h->outG.as<double>(), h->stream));
+    MRC_TRY(s.down(out, h->outG, (size_t)n * sizeof(double)));
+    MRC_HIP(h, hipStreamSynchronize(h->stream));
+    return MRC_OK;
+}
+
 int mrc_window(mrc_handle* h, int64_t n, int a, int b, const double* blocks, double* out) {
     if (!h || !blocks || !out || n < 0) return fail(h, MRC_ERR_INVALID, "mrc_window: bad argument");
     if (n == 0) return MRC_OK;
@@ -431,7 +733,7 @@ int mrc_mdct(mrc_handle* h, int64_t n, int a, int b, const double* blocks, int a
     MRC_TRY(s.up(h->inL, blocks, (size_t)n * S.N * sizeof(double)));
     const size_t szLines = (size_t)n * S.halfN * sizeof(double), szScale = (size_t)n * sizeof(int32_t);
     MRC_HIP(h, h->outG.reserve(szLines)); MRC_HIP(h, h->outA.reserve(szScale));
-    MRC_HIP(h, launch_mdct(S, n, h->inL.as<double>(), nullptr, S.N, nullptr, apply_window != 0, h->outG.as<double>(),
+    MRC_HIP(h, launch_mdct(S, n, h->inL.as<double>(), nullptr, kSampleF64, S.N, nullptr, apply_window != 0, h->outG.as<double>(),
                            h->outA.as<int>(), h->stream));
     MRC_TRY(s.down(lines, h->outG, szLines));
     MRC_TRY(s.down(overall_scale, h->outA, szScale));
@@ -459,10 +761,10 @@ int mrc_smr(mrc_handle* h, int64_t n, int a, int b, const double* blocks, const 
         MRC_TRY(s.up(h->outA, overall_scale, szScale));
         MRC_HIP(h, launch_unscale(n, S.halfN, h->inR.as<double>(), h->outA.as<int>(), h->outG.as<double>(), h->stream));
     } else {
-        MRC_HIP(h, launch_mdct(S, n, h->inL.as<double>(), nullptr, S.N, nullptr, true, h->outG.as<double>(),
+        MRC_HIP(h, launch_mdct(S, n, h->inL.as<double>(), nullptr, kSampleF64, S.N, nullptr, true, h->outG.as<double>(),
                                h->outA.as<int>(), h->stream));
     }
-    MRC_HIP(h, launch_smr(S, n, h->inL.as<double>(), nullptr, S.N, nullptr, h->outG.as<double>(), h->outA.as<int>(),
+    MRC_HIP(h, launch_smr(S, n, h->inL.as<double>(), nullptr, kSampleF64, S.N, nullptr, h->outG.as<double>(), h->outA.as<int>(),
                           h->outC.as<double>(), thresh ? h->outE.as<double>() : nullptr, nullptr, h->exactSpread,
                           h->stream));
     MRC_TRY(s.down(smr, h->outC, szSmr));
@@ -471,8 +773,8 @@ int mrc_smr(mrc_handle* h, int64_t n, int a, int b, const double* blocks, const 
     return MRC_OK;
 }
 
-int mrc_bitalloc(mrc_handle* h, int64_t n_cases, int n_bands, int max_mant_bits, const int32_t* n_lines,
-                 const double* budget, const double* smr, int32_t* bits, int32_t* bits_left) {
+static int bitalloc_host(mrc_handle* h, int64_t n_cases, int n_bands, int max_mant_bits, const int32_t* n_lines,
+                         const double* budget, const double* smr, int32_t* bits, int32_t* bits_left, double* smr_after) {
     if (!h || !n_lines || !budget || !smr || !bits || !bits_left || n_cases < 0 || n_bands < 1 || n_bands > 64)
         return fail(h, MRC_ERR_INVALID, "mrc_bitalloc: bad argument (1 <= n_bands <= 64)");
     if (n_cases == 0) return MRC_OK;
@@ -482,13 +784,27 @@ int mrc_bitalloc(mrc_handle* h, int64_t n_cases, int n_bands, int max_mant_bits,
     MRC_TRY(s.up(h->inAux2, budget, (size_t)n_cases * sizeof(double)));
     MRC_TRY(s.up(h->inL, smr, (size_t)n_cases * n_bands * sizeof(double)));
     const size_t szBits = (size_t)n_cases * n_bands * sizeof(int32_t), szLeft = (size_t)n_cases * sizeof(int32_t);
+    const size_t szSmr = (size_t)n_cases * n_bands * sizeof(double);
     MRC_HIP(h, h->outC.reserve(szBits)); MRC_HIP(h, h->outF.reserve(szLeft));
+    if (smr_after) MRC_HIP(h, h->outG.reserve(szSmr));
     MRC_HIP(h, launch_bitalloc_cases(n_cases, n_bands, max_mant_bits, h->inAux.as<int>(), h->inAux2.as<double>(),
-                                     h->inL.as<double>(), h->outC.as<int>(), h->outF.as<int>(), h->stream));
+                                     h->inL.as<double>(), h->outC.as<int>(), h->outF.as<int>(),
+                                     smr_after ? h->outG.as<double>() : nullptr, h->stream));
     MRC_TRY(s.down(bits, h->outC, szBits));
     MRC_TRY(s.down(bits_left, h->outF, szLeft));
+    if (smr_after) MRC_TRY(s.down(smr_after, h->outG, szSmr));
     MRC_HIP(h, hipStreamSynchronize(h->stream));
     return MRC_OK;
+}
+
+int mrc_bitalloc(mrc_handle* h, int64_t n_cases, int n_bands, int max_mant_bits, const int32_t* n_lines,
+                 const double* budget, const double* smr, int32_t* bits, int32_t* bits_left) {
+    return bitalloc_host(h, n_cases, n_bands, max_mant_bits, n_lines, budget, smr, bits, bits_left, nullptr);
+}
+
+int mrc_bitalloc_inplace(mrc_handle* h, int64_t n_cases, int n_bands, int max_mant_bits, const int32_t* n_lines,
+                         const double* budget, double* smr, int32_t* bits, int32_t* bits_left) {
+    return bitalloc_host(h, n_cases, n_bands, max_mant_bits, n_lines, budget, smr, bits, bits_left, smr);
 }
 
 int mrc_scale_factor(mrc_handle* h, int64_t n, int n_scale_bits, const double* v, const int32_t* n_mant_bits,
@@ -536,6 +852,7 @@ int mrc_decode(mrc_handle* h, int64_t n, int a, int b, int n_streams, const int3
     MRC_TRY(get_shape(h, a, b, &hs));
     const DevShape& S = hs->dev;
     MRC_HIP(h, hipSetDevice(h->device));
+    std::vector<int64_t> offs((size_t)n);                   // (declared before `s`: alive until its drain)
     Staged s{h, h->stream};
     const size_t nOs = n_streams == 2 ? 4 : 1;
     const size_t szBand = (size_t)n * n_streams * S.nBands * sizeof(int32_t), szM = (size_t)n * n_streams * S.halfN * sizeof(int32_t);
@@ -546,7 +863,6 @@ int mrc_decode(mrc_handle* h, int64_t n, int a, int b, int n_streams, const int3
     MRC_TRY(s.up(h->inL, mantissa, szM));
     if (n_streams == 2) MRC_TRY(s.up(h->inR, ms_switch, (size_t)n * S.nBands * sizeof(int32_t)));
     // block i, channel c -> out[(i * n_streams + c) * N]: one plane, per-channel base pointers and a common offset
-    std::vector<int64_t> offs((size_t)n);
     for (int64_t i = 0; i < n; ++i) offs[(size_t)i] = i * n_streams * (int64_t)S.N;
     MRC_TRY(s.up(h->outA, offs.data(), (size_t)n * sizeof(int64_t)));
     MRC_HIP(h, h->outG.reserve(szOut));

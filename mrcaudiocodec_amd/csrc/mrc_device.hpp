@@ -15,13 +15,49 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+// 16-bit PCM code -> signed fraction exactly as the reference's file reader does (pcmfile.py:91-100 through
+// quantize.py:90-111): x = (2 c) / 65535 with ONE rounding (IEEE division), and -32768 -> +0.0 (its magnitude 2^15 is
+// read as a bare sign bit).  The division is replaced by its reciprocal-and-correct form -- q0 = n r,
+// q = fma(fma(-q0, 65535, n), r, q0), r = fl(1/65535) -- which gives the correctly rounded quotient for every one of
+// the 65535 codes (checked exhaustively in exact arithmetic: tests/test_abi.py::test_pcm16_map_is_exact; on the device
+// against the reference's own values: tests/test_gpu_pcm16.py).
+__device__ __forceinline__ double pcm16_to_frac(int c) {
+    const double n = (double)(2 * c);
+    const double r = 0x1.0001000100010p-16;
+    const double q0 = n * r;
+    const double q = fma(fma(-q0, 65535.0, n), r, q0);
+    return c == -32768 ? 0.0 : q;
+}
+// one sample of a channel held as float64 signed fractions or as int16 PCM codes
+__device__ __forceinline__ double sample_of(const double* __restrict__ p, int64_t i) { return p[i]; }
+__device__ __forceinline__ double sample_of(const short* __restrict__ p, int64_t i) { return pcm16_to_frac(p[i]); }
+// an (even, odd) sample pair at an EVEN index: one 16-byte / 4-byte load
+__device__ __forceinline__ double2 pair_of(const double* __restrict__ p, int64_t i) {
+    return *reinterpret_cast<const double2*>(p + i);
+}
+__device__ __forceinline__ double2 pair_of(const short* __restrict__ p, int64_t i) {
+    const int v = *reinterpret_cast<const int*>(p + i);
+    return make_double2(pcm16_to_frac((short)(v & 0xffff)), pcm16_to_frac(v >> 16));
+}
+
 // The four signals of a joint block: L, R, M=(L+R)/2, S=(L-R)/2 (codecThem.py:363-364).
-__device__ __forceinline__ double load_signal(const double* __restrict__ L, const double* __restrict__ R,
-                                               int64_t i, int sig) {
-    if (sig == 0) return L[i];
-    if (sig == 1) return R[i];
-    double l = L[i], r = R[i];
+template <class T>
+__device__ __forceinline__ double load_signal(const T* __restrict__ L, const T* __restrict__ R, int64_t i, int sig) {
+    if (sig == 0) return sample_of(L, i);
+    if (sig == 1) return sample_of(R, i);
+    double l = sample_of(L, i), r = sample_of(R, i);
     return sig == 2 ? (l + r) / 2.0 : (l - r) / 2.0;
+}
+// ... as (even, odd) pairs; `aligned`: index even and base aligned to the pair size (wave-uniform)
+template <class T>
+__device__ __forceinline__ double2 load_signal_pair(const T* __restrict__ L, const T* __restrict__ R, int64_t i, int sig,
+                                                    bool aligned) {
+    if (!aligned)
+        return make_double2(load_signal(L, R, i, sig), load_signal(L, R, i + 1, sig));
+    if (sig == 0) return pair_of(L, i);
+    if (sig == 1) return pair_of(R, i);
+    const double2 l = pair_of(L, i), r = pair_of(R, i);
+    return sig == 2 ? make_double2((l.x + r.x) / 2.0, (l.y + r.y) / 2.0) : make_double2((l.x - r.x) / 2.0, (l.y - r.y) / 2.0);
 }
 
 // MI355X: 8 XCDs, consecutive workgroup ids go to consecutive XCDs.  Maps hardware block id b of a 1-D grid of g

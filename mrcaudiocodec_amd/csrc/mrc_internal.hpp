@@ -10,6 +10,9 @@
 namespace mrc {
 
 constexpr int kMaxRadices = 8;
+// how a channel's samples are held: float64 signed fractions (what pcmfile.py:98 hands the codec) or the file's
+// int16 PCM codes, converted on load (dev::pcm16_to_frac)
+constexpr int kSampleF64 = MRC_SAMPLES_F64, kSampleI16 = MRC_SAMPLES_PCM16;
 constexpr int kMaxBands = MRC_MAX_BANDS;
 
 // Everything a kernel needs to know about one block shape (a,b).  POD, passed by value; the
@@ -59,25 +62,30 @@ void free_shape(HostShape* s);
 int scale_factor_host(double v, int nScaleBits, int nMantBits);
 
 // mrc_kernels.hip -- launchers (enqueue only)
-hipError_t launch_mdct(const DevShape& S, int64_t nFrames, const double* chL, const double* chR,
+hipError_t launch_mdct(const DevShape& S, int64_t nFrames, const void* chL, const void* chR, int fmt,
                        int64_t stride, const int64_t* offsets, bool applyWindow, double* lines, int* oscale,
                        hipStream_t st);
 // mrc_kernels_long.hip -- long-block specialisation (a = b = 1024)
-bool mdct_long_applicable(const DevShape& S, int64_t stride, const int64_t* offsets, const double* chL,
-                          const double* chR);
-hipError_t launch_mdct_long(const DevShape& S, int64_t nFrames, const double* chL, const double* chR,
+bool mdct_long_applicable(const DevShape& S, int64_t stride, const int64_t* offsets, const void* chL,
+                          const void* chR, int fmt);
+hipError_t launch_mdct_long(const DevShape& S, int64_t nFrames, const void* chL, const void* chR, int fmt,
                             int64_t stride, const int64_t* offsets, double* lines, int* oscale, hipStream_t st);
 hipError_t launch_window(const DevShape& S, int64_t nBlocks, const double* in, double* out, hipStream_t st);
 hipError_t launch_unscale(int64_t nBlocks, int halfN, const double* scaled, const int* oscale, double* lines,
                           hipStream_t st);
-hipError_t launch_smr(const DevShape& S, int64_t nFrames, const double* chL, const double* chR,
+hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const void* chR, int fmt,
                       int64_t stride, const int64_t* offsets, const double* lines, const int* oscale,
                       double* smr, double* thresh, double* bandPeak /* [frames*signals][nBands] or null */,
                       bool exactSpread, hipStream_t st);
 hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, const double* lines,
                               const int* oscale, const double* smr, const int* resIn, int* msSwitch,
-                              int* bitAlloc, int* scaleFactor, int* mantissa, int* resOut, double* bandPeakWs,
-                              bool peaksReady /* bandPeakWs already filled by launch_smr */, hipStream_t st);
+                              int* bitAlloc, int* scaleFactor, void* mantissa, int mantFmt /* MRC_MANTISSA_* */,
+                              int* resOut, double* bandPeakWs,
+                              bool peaksReady /* bandPeakWs already filled by launch_smr */,
+                              hipEvent_t* ev /* null or 2 events: after band_stats, after bitalloc */, hipStream_t st);
+hipError_t launch_pcm_to_float(int64_t n, const short* pcm, double* out, hipStream_t st);
+hipError_t launch_quantize_uniform(int64_t n, int nBits, const double* x, long long* out, hipStream_t st);
+hipError_t launch_bark(int64_t n, const double* f, double* out, hipStream_t st);
 size_t alloc_workspace_bytes(const DevShape& S, int64_t nFrames, int joint);   // bandPeakWs size
 // mrc_kernels_decode.hip
 hipError_t launch_decode(const DevShape& S, int64_t nBlocks, int nStreams, const int* oscale, const int* msSwitch,
@@ -89,7 +97,8 @@ hipError_t launch_huffman_gain(const DevShape& S, int64_t nFrames, int nStreams,
                                const int* mantissa, const int* reservoirOut, int* huffTable, int* bitsSaved,
                                int* reservoirNext, hipStream_t st);
 hipError_t launch_bitalloc_cases(int64_t nCases, int nBands, int maxMantBits, const int* nLines,
-                                 const double* budget, const double* smr, int* bits, int* left, hipStream_t st);
+                                 const double* budget, const double* smr, int* bits, int* left,
+                                 double* smrAfter /* nullable: running SMRs after the loop */, hipStream_t st);
 hipError_t launch_scale_factor(int64_t n, int nScaleBits, const double* v, const int* nMantBits, int* out,
                                hipStream_t st);
 hipError_t launch_mantissa(int64_t n, int nScaleBits, const double* x, const int* scale, const int* nMantBits,

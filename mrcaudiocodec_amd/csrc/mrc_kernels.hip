@@ -17,8 +17,9 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // MDCT: one workgroup per (frame, signal)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kThreads) void mdct_kernel(DevShape S, int nsig, const double* __restrict__ chL,
-                                                        const double* __restrict__ chR, int64_t stride,
+template <class SampleT>
+__global__ __launch_bounds__(kThreads) void mdct_kernel(DevShape S, int nsig, const SampleT* __restrict__ chL,
+                                                        const SampleT* __restrict__ chR, int64_t stride,
                                                         const int64_t* __restrict__ offsets,
                                                         const double* __restrict__ win,
                                                         double* __restrict__ lines, int* __restrict__ oscale) {
@@ -73,6 +74,28 @@ __global__ __launch_bounds__(kThreads) void mdct_kernel(DevShape S, int nsig, co
     if (tid == 0) {
         for (int w = 1; w < kThreads / kWave; ++w) peak = fmax(peak, red[w]);
         oscale[blockIdx.x] = scale_factor_dev(peak, S.nScaleBits, 5);       // codecThem.py:322 (nMantBits default)
+    }
+}
+
+// pcmfile.py:91-100: int16 PCM codes -> signed fractions (the map the int16 ingest paths apply on load)
+__global__ void pcm_to_float_kernel(int64_t n, const short* __restrict__ pcm, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = pcm16_to_frac(pcm[i]);
+}
+
+// quantize.py:12-38 / 61-87 elementwise: sign bit << (nBits-1) + magnitude code (x < 0.0 decides the sign: -0.0 is
+// positive, as np.less has it)
+__global__ void quantize_uniform_kernel(int64_t n, int nBits, const double* __restrict__ x, long long* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (x[i] < 0.0 ? (1LL << (nBits - 1)) : 0LL) + mag_code(fabs(x[i]), nBits);
+}
+
+// psychoac.py:27-29 elementwise
+__global__ void bark_kernel(int64_t n, const double* __restrict__ f, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const double q = f[i] / 7500.;
+        out[i] = 13 * atan(0.76 * f[i] / 1000.) + 3.5 * atan(q * q);
     }
 }
 
@@ -174,15 +197,37 @@ __global__ __launch_bounds__(kWave) void ms_switch_kernel(int nBands, int nTotal
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-hipError_t launch_mdct(const DevShape& S, int64_t nFrames, const double* chL, const double* chR, int64_t stride,
+hipError_t launch_mdct(const DevShape& S, int64_t nFrames, const void* chL, const void* chR, int fmt, int64_t stride,
                        const int64_t* offsets, bool applyWindow, double* lines, int* oscale, hipStream_t st) {
     if (nFrames <= 0) return hipSuccess;
-    if (applyWindow && !(reinterpret_cast<uintptr_t>(lines) & 15) && mdct_long_applicable(S, stride, offsets, chL, chR))
-        return launch_mdct_long(S, nFrames, chL, chR, stride, offsets, lines, oscale, st);
+    if (applyWindow && !(reinterpret_cast<uintptr_t>(lines) & 15) && mdct_long_applicable(S, stride, offsets, chL, chR, fmt))
+        return launch_mdct_long(S, nFrames, chL, chR, fmt, stride, offsets, lines, oscale, st);
     const int nsig = chR ? 4 : 1;
     size_t lds = (size_t)(2 * S.N) * sizeof(double);
-    hipLaunchKernelGGL(mdct_kernel, dim3((unsigned)(nFrames * nsig)), dim3(kThreads), lds, st, S, nsig, chL, chR,
-                       stride, offsets, applyWindow ? S.win : nullptr, lines, oscale);
+    if (fmt == kSampleI16)
+        hipLaunchKernelGGL(mdct_kernel<short>, dim3((unsigned)(nFrames * nsig)), dim3(kThreads), lds, st, S, nsig,
+                           (const short*)chL, (const short*)chR, stride, offsets, applyWindow ? S.win : nullptr, lines, oscale);
+    else
+        hipLaunchKernelGGL(mdct_kernel<double>, dim3((unsigned)(nFrames * nsig)), dim3(kThreads), lds, st, S, nsig,
+                           (const double*)chL, (const double*)chR, stride, offsets, applyWindow ? S.win : nullptr, lines, oscale);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantize_uniform(int64_t n, int nBits, const double* x, long long* out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(quantize_uniform_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, nBits, x, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_bark(int64_t n, const double* f, double* out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(bark_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, f, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_pcm_to_float(int64_t n, const short* pcm, double* out, hipStream_t st) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pcm_to_float_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, pcm, out);
     return hipGetLastError();
 }
 

@@ -130,7 +130,7 @@ __global__ __launch_bounds__(kWave) void bitalloc_cases_kernel(int64_t nCases, i
                                                                const int* __restrict__ nLines,
                                                                const double* __restrict__ budget,
                                                                const double* __restrict__ smr, int* __restrict__ bitsOut,
-                                                               int* __restrict__ left) {
+                                                               int* __restrict__ left, double* __restrict__ smrAfter) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     double* run = lds;
@@ -148,18 +148,21 @@ __global__ __launch_bounds__(kWave) void bitalloc_cases_kernel(int64_t nCases, i
     if (active) {
         left[c] = (int)l;
         for (int i = 0; i < nBands; ++i) bitsOut[c * nBands + i] = bits[i * kWave + lane];
+        // bitalloc.py:132-151 updates the caller's SMR array in place: the running values after the loop
+        if (smrAfter) for (int i = 0; i < nBands; ++i) smrAfter[c * nBands + i] = run[i * kWave + lane];
     }
 }
 
 // ------------------------------------------------------------------------------------------------
 // scale factors + mantissas: one wavefront per (frame, stream)
 // ------------------------------------------------------------------------------------------------
+template <class OutT>                                  // int32 plane, or uint16 (codes are at most 16 bits wide: codecThem.py:292-293)
 __global__ __launch_bounds__(kWave) void quantize_kernel(DevShape S, int joint, const double* __restrict__ lines,
                                                          const int* __restrict__ oscale,
                                                          const double* __restrict__ bandPeak,
                                                          const int* __restrict__ msSwitch,
                                                          const int* __restrict__ bitAlloc,
-                                                         int* __restrict__ scaleFactor, int* __restrict__ mantissa) {
+                                                         int* __restrict__ scaleFactor, OutT* __restrict__ mantissa) {
     __shared__ int sBa[kMaxBands], sSf[kMaxBands], sSig[kMaxBands], sOsc[kMaxBands];
     __shared__ unsigned char sBand[kBandLds];            // band of every line (copy of S.bandOfLine)
     const int lane = threadIdx.x;
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(kWave) void quantize_kernel(DevShape S, int joint, 
         scaleFactor[(f * nstream + strm) * nb + lane] = sf;
     }
     __syncthreads();
-    int* out = mantissa + (f * nstream + strm) * M;
+    OutT* out = mantissa + (f * nstream + strm) * M;
     constexpr int kBatch = 4;                            // lines in flight per lane
     for (int k0 = lane; k0 < M; k0 += kWave * kBatch) {
         int bnd[kBatch], sc[kBatch];
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(kWave) void quantize_kernel(DevShape S, int joint, 
             const int k = k0 + u * kWave;
             if (k < M) {
                 const int ba = sBa[bnd[u]];
-                out[k] = ba ? mantissa_dev(ldexp(x[u], sc[u]), sSf[bnd[u]], S.nScaleBits, ba) : 0;   // codecThem.py:348-349
+                out[k] = (OutT)(ba ? mantissa_dev(ldexp(x[u], sc[u]), sSf[bnd[u]], S.nScaleBits, ba) : 0);   // codecThem.py:348-349
             }
         }
     }
@@ -221,27 +224,34 @@ size_t alloc_workspace_bytes(const DevShape& S, int64_t nFrames, int joint) {
 
 hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, const double* lines, const int* oscale,
                               const double* smr, const int* resIn, int* msSwitch, int* bitAlloc, int* scaleFactor,
-                              int* mantissa, int* resOut, double* bandPeakWs, bool peaksReady, hipStream_t st) {
+                              void* mantissa, int mantFmt, int* resOut, double* bandPeakWs, bool peaksReady,
+                              hipEvent_t* ev /* null, or 2 events: after band_stats, after bitalloc */, hipStream_t st) {
     if (nFrames <= 0) return hipSuccess;
     const int nTot = (joint ? 2 : 1) * S.nBands;
     // the per-band peaks come from smr_kernel on the full path; this kernel is then only the M/S decision (joint)
     if (joint || !peaksReady)
         hipLaunchKernelGGL(band_stats_kernel, dim3((unsigned)nFrames), dim3(kWave), 0, st, S, joint, peaksReady ? 0 : 1,
                            lines, msSwitch, bandPeakWs);
+    if (ev) (void)hipEventRecord(ev[0], st);
     const size_t lds = (size_t)nTot * kWave * (sizeof(double) + 1) + (size_t)nTot * sizeof(int);
     hipLaunchKernelGGL(bitalloc_kernel, dim3((unsigned)((nFrames + kWave - 1) / kWave)), dim3(kWave), lds, st, S, joint,
                        nFrames, smr, msSwitch, resIn, bitAlloc, resOut);
-    hipLaunchKernelGGL(quantize_kernel, dim3((unsigned)(nFrames * (joint ? 2 : 1))), dim3(kWave), 0, st, S, joint, lines,
-                       oscale, bandPeakWs, msSwitch, bitAlloc, scaleFactor, mantissa);
+    if (ev) (void)hipEventRecord(ev[1], st);
+    if (mantFmt == MRC_MANTISSA_I16)
+        hipLaunchKernelGGL(quantize_kernel<unsigned short>, dim3((unsigned)(nFrames * (joint ? 2 : 1))), dim3(kWave), 0, st, S, joint,
+                           lines, oscale, bandPeakWs, msSwitch, bitAlloc, scaleFactor, (unsigned short*)mantissa);
+    else
+        hipLaunchKernelGGL(quantize_kernel<int>, dim3((unsigned)(nFrames * (joint ? 2 : 1))), dim3(kWave), 0, st, S, joint,
+                           lines, oscale, bandPeakWs, msSwitch, bitAlloc, scaleFactor, (int*)mantissa);
     return hipGetLastError();
 }
 
 hipError_t launch_bitalloc_cases(int64_t nCases, int nBands, int maxMantBits, const int* nLines, const double* budget,
-                                 const double* smr, int* bits, int* left, hipStream_t st) {
+                                 const double* smr, int* bits, int* left, double* smrAfter, hipStream_t st) {
     if (nCases <= 0) return hipSuccess;
     const size_t lds = (size_t)nBands * kWave * (sizeof(double) + 1) + (size_t)nBands * sizeof(int);
     hipLaunchKernelGGL(bitalloc_cases_kernel, dim3((unsigned)((nCases + kWave - 1) / kWave)), dim3(kWave), lds, st,
-                       nCases, nBands, maxMantBits, nLines, budget, smr, bits, left);
+                       nCases, nBands, maxMantBits, nLines, budget, smr, bits, left, smrAfter);
     return hipGetLastError();
 }
 

@@ -17,20 +17,18 @@
 //
 // Arithmetic: same formulas as the generic mdct_kernel (window.py:104-121, mdct.py:63-76,
 // codecThem.py:321-322), float64, file compiled with -ffp-contract=off.
-#include "mrc_internal.hpp"
+#include "mrc_device.hpp"
 
 namespace mrc {
 namespace {
 
-constexpr int kWave = 64;
+using dev::kWave;
 constexpr int kWavesPerBlock = 4;
 constexpr int kM = 1024, kQ = 512;                   // N = 2048: N/2 lines, N/4-point FFT
 constexpr int kWaveLds = 2048;                       // doubles per wave (16 KiB)
 constexpr int kRun = 16;                             // units per wave
 
-__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
-    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
+using dev::cmul;
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ double2 mul_mi(double2 a) { return make_double2(a.y, -a.x); }     // a * (-i)
@@ -106,28 +104,14 @@ __device__ __forceinline__ int scale_factor20(double v, int nScaleBits) {       
     return lz < cap ? lz : cap;
 }
 
-// 16 bytes per lane when the sample offset is even (always, for strided layouts); an explicit offset may be odd,
-// then two 8-byte loads (wave-uniform choice)
-__device__ __forceinline__ double2 load2(const double* __restrict__ p, bool aligned) {
-    if (aligned) return *reinterpret_cast<const double2*>(p);
-    return make_double2(p[0], p[1]);
-}
-
-template <int NSIG>
-__device__ __forceinline__ void load_pair(const double* __restrict__ L, const double* __restrict__ R, int64_t i, int sig,
+// one (even, odd) sample pair per lane: 16 bytes of float64 signed fractions or 4 bytes of int16 PCM codes when the
+// sample offset is even (always, for strided layouts); an explicit offset may be odd, then two scalar loads
+// (wave-uniform choice)
+template <int NSIG, class T>
+__device__ __forceinline__ void load_pair(const T* __restrict__ L, const T* __restrict__ R, int64_t i, int sig,
                                           double* e, double* o, bool aligned = true) {
-    if (NSIG == 1 || sig == 0) {
-        double2 v = load2(L + i, aligned);
-        *e = v.x; *o = v.y;
-    } else if (sig == 1) {
-        double2 v = load2(R + i, aligned);
-        *e = v.x; *o = v.y;
-    } else {
-        double2 l = load2(L + i, aligned);
-        double2 r = load2(R + i, aligned);
-        if (sig == 2) { *e = (l.x + r.x) / 2.0; *o = (l.y + r.y) / 2.0; }       // codecThem.py:363
-        else { *e = (l.x - r.x) / 2.0; *o = (l.y - r.y) / 2.0; }                // codecThem.py:364
-    }
+    const double2 v = dev::load_signal_pair(L, R, i, NSIG == 1 ? 0 : sig, aligned);     // codecThem.py:363-364 for M, S
+    *e = v.x; *o = v.y;
 }
 
 // pre[lane + 64 r] = pre[lane] * W32^r and post[lane + 64 q] = post[lane] * W32^q (both tables are unit-circle
@@ -138,9 +122,9 @@ template <int R> __device__ __forceinline__ double2 twiddle_lane(double2 v, doub
     return mul_w32<R == 0 ? 1 : R>(t);
 }
 
-template <int NSIG, bool REUSE>
+template <int NSIG, bool REUSE, class T>
 __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void mdct_long_kernel(
-    DevShape S, int64_t nUnits, const double* __restrict__ chL, const double* __restrict__ chR, int64_t stride,
+    DevShape S, int64_t nUnits, const T* __restrict__ chL, const T* __restrict__ chR, int64_t stride,
     const int64_t* __restrict__ offsets, double* __restrict__ lines, int* __restrict__ oscale) {
     __shared__ __attribute__((aligned(16))) double smem[kWavesPerBlock * kWaveLds + 2 * kQ];
     const int lane = threadIdx.x & (kWave - 1);
@@ -167,7 +151,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void mdct_long_kernel(
     if (REUSE && firstUnit < nUnits) {
         const int64_t off = firstUnit * stride;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) load_pair<1>(chL, chR, off + 2 * (lane + 64 * c), 0, &rawE[c], &rawO[c]);
+        for (int c = 0; c < 8; ++c) load_pair<1, T>(chL, chR, off + 2 * (lane + 64 * c), 0, &rawE[c], &rawO[c]);
     }
 
     for (int it = 0; it < kRun; ++it) {
@@ -188,7 +172,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void mdct_long_kernel(
             if (REUSE && c < 8) {
                 e = rawE[c]; o = rawO[c];
             } else {
-                load_pair<NSIG>(chL, chR, off + 2 * i, sig, &e, &o, aligned);
+                load_pair<NSIG, T>(chL, chR, off + 2 * i, sig, &e, &o, aligned);
                 if (REUSE) { rawE[c & 7] = e; rawO[c & 7] = o; }
             }
             yE[i] = e * wE[c];
@@ -263,31 +247,39 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void mdct_long_kernel(
 
 }  // namespace
 
-bool mdct_long_applicable(const DevShape& S, int64_t stride, const int64_t* offsets, const double* chL,
-                          const double* chR) {
+bool mdct_long_applicable(const DevShape& S, int64_t stride, const int64_t* offsets, const void* chL, const void* chR,
+                          int fmt) {
     if (S.a != 1024 || S.b != 1024) return false;
     if (!offsets && stride % 2 != 0) return false;   // (explicit offsets: the kernel checks each one's parity itself)
-    if ((reinterpret_cast<uintptr_t>(chL) & 15) || (chR && (reinterpret_cast<uintptr_t>(chR) & 15))) return false;
+    const uintptr_t mask = fmt == kSampleI16 ? 3 : 15;              // one (even, odd) pair per load
+    if ((reinterpret_cast<uintptr_t>(chL) & mask) || (chR && (reinterpret_cast<uintptr_t>(chR) & mask))) return false;
     return true;
 }
 
-hipError_t launch_mdct_long(const DevShape& S, int64_t nFrames, const double* chL, const double* chR, int64_t stride,
-                            const int64_t* offsets, double* lines, int* oscale, hipStream_t st) {
-    if (nFrames <= 0) return hipSuccess;
+template <class T>
+static void launch_long_t(const DevShape& S, int64_t nFrames, const T* chL, const T* chR, int64_t stride,
+                          const int64_t* offsets, double* lines, int* oscale, hipStream_t st) {
     const int nsig = chR ? 4 : 1;
     const int64_t nUnits = nFrames * nsig;
     const int64_t perBlock = (int64_t)kWavesPerBlock * kRun;
     const unsigned grid = (unsigned)((nUnits + perBlock - 1) / perBlock);
     const dim3 block(kWave * kWavesPerBlock);
     if (nsig == 4)
-        hipLaunchKernelGGL((mdct_long_kernel<4, false>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, offsets,
+        hipLaunchKernelGGL((mdct_long_kernel<4, false, T>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, offsets,
                            lines, oscale);
     else if (!offsets && stride == kM)               // hop-overlapped stream: consecutive frames share a hop
-        hipLaunchKernelGGL((mdct_long_kernel<1, true>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, offsets,
+        hipLaunchKernelGGL((mdct_long_kernel<1, true, T>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, offsets,
                            lines, oscale);
     else
-        hipLaunchKernelGGL((mdct_long_kernel<1, false>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, offsets,
+        hipLaunchKernelGGL((mdct_long_kernel<1, false, T>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, offsets,
                            lines, oscale);
+}
+
+hipError_t launch_mdct_long(const DevShape& S, int64_t nFrames, const void* chL, const void* chR, int fmt, int64_t stride,
+                            const int64_t* offsets, double* lines, int* oscale, hipStream_t st) {
+    if (nFrames <= 0) return hipSuccess;
+    if (fmt == kSampleI16) launch_long_t(S, nFrames, (const short*)chL, (const short*)chR, stride, offsets, lines, oscale, st);
+    else launch_long_t(S, nFrames, (const double*)chL, (const double*)chR, stride, offsets, lines, oscale, st);
     return hipGetLastError();
 }
 

@@ -327,9 +327,9 @@ __device__ unsigned long long gPhaseCycles[16];
 #define MRC_PROFILE_SKIP 0                       // 1 far field, 2 direct pairs, 4 partial pairs, 8 chunk tail
 #endif
 
-template <bool EXACT>
-__global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, int nsig, const double* __restrict__ chL,
-                                                       const double* __restrict__ chR, int64_t stride,
+template <bool EXACT, class SampleT>
+__global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, int nsig, const SampleT* __restrict__ chL,
+                                                       const SampleT* __restrict__ chR, int64_t stride,
                                                        const int64_t* __restrict__ offsets,
                                                        const double* __restrict__ lines,
                                                        const int* __restrict__ oscale, double* __restrict__ smr,
@@ -379,13 +379,17 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     // Hann window (window.py:28-45) and real FFT through an H = N/2 point complex FFT.  All global loads of a
     // thread are issued before the first use: one memory round trip per phase instead of one per iteration.
     constexpr int kPre = 4;
+    // (even, odd) sample pairs come as ONE load each when the block starts at an even sample of an aligned channel
+    const bool pairAligned = !(off & 1) && !(reinterpret_cast<uintptr_t>(chL) & (2 * sizeof(SampleT) - 1)) &&
+                             (!chR || !(reinterpret_cast<uintptr_t>(chR) & (2 * sizeof(SampleT) - 1)));
     for (int n0 = tid; n0 < H; n0 += kThreads * kPre) {
         double e[kPre], o[kPre], he[kPre], ho[kPre];
 #pragma unroll
         for (int u = 0; u < kPre; ++u) {
             const int n = min(n0 + u * kThreads, H - 1);
-            e[u] = load_signal(chL, chR, off + 2 * n, sig);
-            o[u] = load_signal(chL, chR, off + 2 * n + 1, sig);
+            const double2 eo = load_signal_pair(chL, chR, off + 2 * n, sig, pairAligned);
+            e[u] = eo.x;
+            o[u] = eo.y;
             he[u] = S.hann[2 * n];
             ho[u] = S.hann[2 * n + 1];
         }
@@ -871,7 +875,7 @@ extern "C" int mrc_debug_phase_cycles(unsigned long long* out16, int reset) {
 }
 #endif
 
-hipError_t launch_smr(const DevShape& S, int64_t nFrames, const double* chL, const double* chR, int64_t stride,
+hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const void* chR, int fmt, int64_t stride,
                       const int64_t* offsets, const double* lines, const int* oscale, double* smr, double* thresh,
                       double* bandPeak, bool exactSpread, hipStream_t st) {
     if (nFrames <= 0) return hipSuccess;
@@ -901,12 +905,13 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const double* chL, con
         else { total += total & 1; lay.twOff = total; total += H / 2; }
     }
     const size_t lds = (size_t)total * sizeof(double);
-    if (exactSpread)
-        hipLaunchKernelGGL(smr_kernel<true>, dim3((unsigned)(nFrames * nsig)), dim3(kThreads), lds, st, S, nsig, chL,
-                           chR, stride, offsets, lines, oscale, smr, thresh, bandPeak, lay);
-    else
-        hipLaunchKernelGGL(smr_kernel<false>, dim3((unsigned)(nFrames * nsig)), dim3(kThreads), lds, st, S, nsig, chL,
-                           chR, stride, offsets, lines, oscale, smr, thresh, bandPeak, lay);
+    const dim3 grid((unsigned)(nFrames * nsig)), block(kThreads);
+#define MRC_SMR_LAUNCH(EX, TY)                                                                                       \
+    hipLaunchKernelGGL((smr_kernel<EX, TY>), grid, block, lds, st, S, nsig, (const TY*)chL, (const TY*)chR, stride,  \
+                       offsets, lines, oscale, smr, thresh, bandPeak, lay)
+    if (fmt == kSampleI16) { if (exactSpread) MRC_SMR_LAUNCH(true, short); else MRC_SMR_LAUNCH(false, short); }
+    else { if (exactSpread) MRC_SMR_LAUNCH(true, double); else MRC_SMR_LAUNCH(false, double); }
+#undef MRC_SMR_LAUNCH
     return hipGetLastError();
 }
 

@@ -30,7 +30,7 @@ def test_library_exports_every_header_symbol():
     for n in names:
         assert hasattr(raw, n), "libmrc_hip.so does not export %s" % n
         assert n in _lib.EXPORTS, "ctypes binding does not declare %s" % n
-    assert _lib.lib.mrc_version() == 100
+    assert _lib.lib.mrc_version() == 200
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -102,3 +102,26 @@ def test_table_log10_accuracy(tmp_path):
     max_ulp, max_abs = map(float, subprocess.check_output([exe]).split())
     assert max_ulp <= 0.6, max_ulp
     assert max_abs <= 4e-17, max_abs
+
+
+def test_pcm16_map_is_exact():
+    """dev::pcm16_to_frac (csrc/mrc_device.hpp) replaces the reference's IEEE division 2c/65535 (pcmfile.py:91-100 via
+    quantize.py:90-111) by q0 = n r, q = fma(fma(-q0, 65535, n), r, q0) with r = fl(1/65535).  Checked here for EVERY
+    16-bit code in exact rational arithmetic (each device operation rounds once: Fraction -> float is that rounding),
+    against the values the reference's own function returned for the recorded codes."""
+    from fractions import Fraction
+    r = float.fromhex("0x1.0001000100010p-16")
+    assert r == float(Fraction(1, 65535))
+
+    def dev_map(c):
+        if c == -32768:
+            return 0.0
+        n = float(2 * c)
+        q0 = float(Fraction(n) * Fraction(r))
+        rem = float(Fraction(n) - Fraction(q0) * 65535)
+        return float(Fraction(q0) + Fraction(rem) * Fraction(r))
+    for c in range(-32768, 32768):
+        want = 0.0 if c == -32768 else (2.0 * c) / 65535.0
+        assert dev_map(c) == want, c
+    g = np.load(os.path.join(ROOT, "tests", "golden", "ref_encode.npz"), allow_pickle=False)
+    assert [dev_map(int(c)) for c in g["pcmmap_in"]] == list(g["pcmmap_out"])

@@ -73,3 +73,24 @@ def test_two_rank_sharded_encode_equals_unsharded(tmp_path):
     assert [int(p["first"]) for p in parts] == [0, 4]
     for k in ("mantissa", "bit_alloc", "ms_switch", "reservoir_out"):
         assert np.array_equal(np.concatenate([p[k] for p in parts]), ref[k]), k
+
+
+def test_bench_stream_generator_shards_are_slices_of_one_stream():
+    """bench.py's counter-based content: what rank r generates for its frame range is exactly its slice (with the
+    one-hop halo) of the single global stream -- for the mono (configs[1]), stereo (configs[4]) and block-switching
+    content."""
+    torch = pytest.importorskip("torch")
+    import bench
+    from mrcaudiocodec_amd.shard import shard_frames, shard_samples
+    dev = torch.device("cpu")
+    total = 37
+    for kind in ("c2", "c3", "c4"):
+        whole = bench.stream_slice(torch, dev, kind, 0, total)
+        for world in (2, 3, 8):
+            for rank in range(world):
+                first, n = shard_frames(total, world, rank)
+                lo, hi = shard_samples(first, n, 1024)
+                part = bench.stream_slice(torch, dev, kind, first, n)
+                for ch in range(len(whole)):
+                    assert torch.equal(part[ch], whole[ch][lo:hi]), (kind, world, rank)
+    assert not whole[0][:1024].any() and whole[0].dtype == torch.int16
