@@ -958,23 +958,25 @@ int mrc_ms_switch(mrc_handle* h, int64_t n_blocks, int n_bands, const int32_t* n
         n_bands > MRC_MAX_BANDS)
         return fail(h, MRC_ERR_INVALID, "mrc_ms_switch: bad argument");
     if (n_blocks == 0) return MRC_OK;
-    std::vector<int> lo(n_bands), cnt(n_bands);
+    std::vector<int> lo(n_bands), cnt(n_bands), plan;
     int total = 0;
     for (int i = 0; i < n_bands; ++i) {
         if (n_lines[i] < 0) return fail(h, MRC_ERR_INVALID, "mrc_ms_switch: negative band size");
         lo[i] = total; cnt[i] = n_lines[i]; total += n_lines[i];
     }
+    int nLeaves = 0, nInternal = 0;
+    ms_plan(lo, cnt, &plan, &nLeaves, &nInternal);
+    if (nLeaves + nInternal > 64) return fail(h, MRC_ERR_INVALID, "mrc_ms_switch: band table too fine (more than 64 summation nodes)");
     MRC_HIP(h, hipSetDevice(h->device));
-    Staged s{h, h->stream};
-    MRC_TRY(s.up(h->inAux, lo.data(), (size_t)n_bands * sizeof(int)));
-    MRC_TRY(s.up(h->inAux2, cnt.data(), (size_t)n_bands * sizeof(int)));
+    Staged s{h, h->stream};                                 // (plan, lo, cnt are declared before it: alive until its drain)
+    MRC_TRY(s.up(h->inAux, plan.data(), plan.size() * sizeof(int)));
     MRC_TRY(s.up(h->inL, lines_left, (size_t)n_blocks * total * sizeof(double)));
     MRC_TRY(s.up(h->inR, lines_right, (size_t)n_blocks * total * sizeof(double)));
     MRC_HIP(h, h->outC.reserve((size_t)n_blocks * n_bands * sizeof(int32_t)));
-    MRC_HIP(h, launch_ms_switch(n_blocks, n_bands, total, h->inAux.as<int>(), h->inAux2.as<int>(), h->inL.as<double>(),
-                                h->inR.as<double>(), h->outC.as<int>(), h->stream));
+    MRC_HIP(h, launch_ms_switch(n_blocks, n_bands, nLeaves, nInternal, h->inAux.as<int>(), h->inL.as<double>(),
+                                h->inR.as<double>(), total, h->outC.as<int>(), h->stream));
     MRC_TRY(s.down(ms_switch, h->outC, (size_t)n_blocks * n_bands * sizeof(int32_t)));
-    MRC_HIP(h, hipStreamSynchronize(h->stream));    // lo/cnt (pageable host vectors) stay alive until here
+    MRC_HIP(h, hipStreamSynchronize(h->stream));
     return MRC_OK;
 }
 

@@ -197,14 +197,14 @@ struct TwQuarter {
 // POW2: p (the product of the radices already done) is a power of two -- true until the first radix-3
 // pass, factor() puts the 3s last -- so the index split is a mask and a shift instead of div/mod.
 // The first pass (p == 1) has unit twiddles and skips them.
-template <int R, bool POW2, class TW>
+template <int R, bool POW2, class TW, int NT = kThreads>
 __device__ __forceinline__ void fft_pass(const double2* __restrict__ in, double2* __restrict__ out, int n, int p,
                                          const TW& W, int tid) {
     const int T = n / R;
     const int tws = n / (p * R);
     const int lp = 31 - __clz(p);
     const bool first = p == 1;
-    for (int i = tid; i < T; i += kThreads) {
+    for (int i = tid; i < T; i += NT) {
         const int k = POW2 ? (i & (p - 1)) : (i % p);
         const int j = (POW2 ? (i >> lp) : (i / p)) * (p * R) + k;
         double2 u[R];
@@ -221,19 +221,19 @@ __device__ __forceinline__ void fft_pass(const double2* __restrict__ in, double2
 }
 
 // Runs all passes; returns the buffer (A or B) that holds the natural-order result.
-template <class TW>
+template <class TW, int NT = kThreads>
 __device__ __forceinline__ double2* fft_lds(double2* A, double2* B, int n, const int* rad, int nrad, const TW& W,
                                             int tid) {
     int p = 1;
     for (int s = 0; s < nrad; ++s) {
         const int R = rad[s];
         const bool pow2 = (p & (p - 1)) == 0;
-        if (R == 4 && pow2) fft_pass<4, true>(A, B, n, p, W, tid);
-        else if (R == 2 && pow2) fft_pass<2, true>(A, B, n, p, W, tid);
-        else if (R == 4) fft_pass<4, false>(A, B, n, p, W, tid);
-        else if (R == 2) fft_pass<2, false>(A, B, n, p, W, tid);
-        else if (pow2) fft_pass<3, true>(A, B, n, p, W, tid);
-        else fft_pass<3, false>(A, B, n, p, W, tid);
+        if (R == 4 && pow2) fft_pass<4, true, TW, NT>(A, B, n, p, W, tid);
+        else if (R == 2 && pow2) fft_pass<2, true, TW, NT>(A, B, n, p, W, tid);
+        else if (R == 4) fft_pass<4, false, TW, NT>(A, B, n, p, W, tid);
+        else if (R == 2) fft_pass<2, false, TW, NT>(A, B, n, p, W, tid);
+        else if (pow2) fft_pass<3, true, TW, NT>(A, B, n, p, W, tid);
+        else fft_pass<3, false, TW, NT>(A, B, n, p, W, tid);
         __syncthreads();
         double2* t = A; A = B; B = t;
         p *= R;
@@ -241,22 +241,28 @@ __device__ __forceinline__ double2* fft_lds(double2* A, double2* B, int n, const
     return A;
 }
 // n a power of two (radix 4 / 2 passes only), twiddles from the LDS quadrant
+template <int NT = kThreads>
 __device__ __forceinline__ double2* fft_lds_pow2(double2* A, double2* B, int n, const int* rad, int nrad,
                                                  const TwQuarter& W, int tid) {
     int p = 1;
     for (int s = 0; s < nrad; ++s) {
         const int R = rad[s];
-        if (R == 4) fft_pass<4, true>(A, B, n, p, W, tid);
-        else fft_pass<2, true>(A, B, n, p, W, tid);
+        if (R == 4) fft_pass<4, true, TwQuarter, NT>(A, B, n, p, W, tid);
+        else fft_pass<2, true, TwQuarter, NT>(A, B, n, p, W, tid);
         __syncthreads();
         double2* t = A; A = B; B = t;
         p *= R;
     }
     return A;
 }
+template <int NT = kThreads>
+__device__ __forceinline__ double2* fft_lds_global(double2* A, double2* B, int n, const int* rad, int nrad,
+                                                   const double2* __restrict__ W, int tid) {
+    return fft_lds<TwGlobal, NT>(A, B, n, rad, nrad, TwGlobal{W}, tid);
+}
 __device__ __forceinline__ double2* fft_lds(double2* A, double2* B, int n, const int* rad, int nrad,
                                             const double2* __restrict__ W, int tid) {
-    return fft_lds(A, B, n, rad, nrad, TwGlobal{W}, tid);
+    return fft_lds_global<kThreads>(A, B, n, rad, nrad, W, tid);
 }
 
 // NumPy's pairwise summation of a contiguous run (np.sum over a 1-D slice), restated so that the

@@ -47,6 +47,10 @@ struct DevShape {
     const unsigned short* loLine;    // [halfN] first line j with zb[j] - zb[k] >= -1/2 (search hint)
     const unsigned short* hiLine;    // [halfN] first line j with zb[j] - zb[k] > 1/2, halfN if none (search hint)
     double linesPerHz;               // N / sampleRate
+    // NumPy's pairwise summation of every band's lines as a static tree (ms_plan): msLeaves (lo, n) runs of <= 128
+    // lines, then internal nodes (left, right) in an order where children come first, then the root node of each band
+    const int* msPlan;               // [2 msLeaves + 2 msInternal + nBands]
+    int msLeaves, msInternal;
 };
 
 struct HostShape {
@@ -57,6 +61,10 @@ struct HostShape {
 
 // mrc_tables.cpp
 bool band_table(const mrc_config& cfg, int a, int b, std::vector<int>* count);   // host only
+// The summation tree np.sum walks over each band's contiguous run of lines (pairwise summation: runs of more than 128
+// elements are halved, the first half rounded down to a multiple of 8).  -> plan laid out as DevShape::msPlan.
+void ms_plan(const std::vector<int>& bandLo, const std::vector<int>& bandN, std::vector<int>* plan, int* nLeaves,
+             int* nInternal);
 bool build_shape(const mrc_config& cfg, int a, int b, HostShape* out, std::string* err);
 void free_shape(HostShape* s);
 int scale_factor_host(double v, int nScaleBits, int nMantBits);
@@ -107,7 +115,8 @@ hipError_t launch_transient_peaks(int64_t nHops, int nCh, int hop, int nShort, i
                                   const double* streams, int64_t chStride, double* peaks, hipStream_t st);
 hipError_t launch_stereo_masking(int64_t n, const double* mid, const double* side, const double* z, double* outMid,
                                  double* outSide, hipStream_t st);
-hipError_t launch_ms_switch(int64_t nBlocks, int nBands, int nTotal, const int* bandLo, const int* bandN,
-                            const double* L, const double* R, int* out, hipStream_t st);
+hipError_t launch_ms_switch(int64_t nBlocks, int nBands, int nLeaves, int nInternal, const int* plan /* device */,
+                            const double* L, const double* R, int64_t blockStride /* doubles between blocks */, int* out,
+                            hipStream_t st);
 
 }  // namespace mrc

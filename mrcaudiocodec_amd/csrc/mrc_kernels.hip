@@ -17,14 +17,14 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 // MDCT: one workgroup per (frame, signal)
 // ------------------------------------------------------------------------------------------------
-template <class SampleT>
-__global__ __launch_bounds__(kThreads) void mdct_kernel(DevShape S, int nsig, const SampleT* __restrict__ chL,
+template <class SampleT, int NT>
+__global__ __launch_bounds__(NT) void mdct_kernel(DevShape S, int nsig, const SampleT* __restrict__ chL,
                                                         const SampleT* __restrict__ chR, int64_t stride,
                                                         const int64_t* __restrict__ offsets,
                                                         const double* __restrict__ win,
                                                         double* __restrict__ lines, int* __restrict__ oscale) {
     extern __shared__ double smem[];
-    __shared__ double red[kThreads / kWave];
+    __shared__ double red[NT / kWave];
     const int tid = threadIdx.x;
     const int N = S.N, M = S.halfN, Q = S.Q;
     const int64_t f = blockIdx.x / nsig;
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(kThreads) void mdct_kernel(DevShape S, int nsig, co
 
     // window (window.py:104-121) + signed circular shift by (b-a)/4: the transform kernel is
     // anti-periodic in N, so X(n0=(b+1)/2) of x equals the standard-phase MDCT of the shifted block.
-    for (int n = tid; n < N; n += kThreads) {
+    for (int n = tid; n < N; n += NT) {
         double v = load_signal(chL, chR, off + n, sig);
         if (win) v = v * win[n];
         int m = n + S.shift;
@@ -46,16 +46,16 @@ __global__ __launch_bounds__(kThreads) void mdct_kernel(DevShape S, int nsig, co
     }
     __syncthreads();
     // fold N -> N/2 (DCT-IV input u) and pack pairs into Q complex points with the pre-twiddle
-    for (int n = tid; n < Q; n += kThreads) {
+    for (int n = tid; n < Q; n += NT) {
         const int j0 = 2 * n, j1 = M - 1 - 2 * n, h = Q;
         double u0 = (j0 < h) ? (-y[3 * h - 1 - j0] - y[3 * h + j0]) : (y[j0 - h] - y[3 * h - 1 - j0]);
         double u1 = (j1 < h) ? (-y[3 * h - 1 - j1] - y[3 * h + j1]) : (y[j1 - h] - y[3 * h - 1 - j1]);
         A[n] = cmul(make_double2(u0, u1), S.pre[n]);
     }
     __syncthreads();
-    double2* T = fft_lds(A, B, Q, S.radQ, S.nRadQ, S.wQ, tid);
+    double2* T = fft_lds_global<NT>(A, B, Q, S.radQ, S.nRadQ, S.wQ, tid);
     // post-twiddle; y is free again (all reads of it happened before the FFT's first barrier)
-    for (int k = tid; k < Q; k += kThreads) {
+    for (int k = tid; k < Q; k += NT) {
         double2 c = cmul(T[k], S.post[k]);
         y[2 * k] = S.twoOverN * c.x;
         y[M - 1 - 2 * k] = S.twoOverN * (-c.y);
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kThreads) void mdct_kernel(DevShape S, int nsig, co
     __syncthreads();
     double peak = 0.0;
     double* dst = lines + ((int64_t)blockIdx.x) * M;
-    for (int k = tid; k < M; k += kThreads) {
+    for (int k = tid; k < M; k += NT) {
         double v = y[k];
         dst[k] = v;
         peak = fmax(peak, fabs(v));
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kThreads) void mdct_kernel(DevShape S, int nsig, co
     if ((tid & (kWave - 1)) == 0) red[tid / kWave] = peak;
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < kThreads / kWave; ++w) peak = fmax(peak, red[w]);
+        for (int w = 1; w < NT / kWave; ++w) peak = fmax(peak, red[w]);
         oscale[blockIdx.x] = scale_factor_dev(peak, S.nScaleBits, 5);       // codecThem.py:322 (nMantBits default)
     }
 }
@@ -184,12 +184,58 @@ __global__ void stereo_masking_kernel(int64_t n, const double* __restrict__ mid,
     outSide[i] = fmax(s, fmin(m, mld * m));
 }
 
-__global__ __launch_bounds__(kWave) void ms_switch_kernel(int nBands, int nTotal, const int* __restrict__ bandLo,
-                                                          const int* __restrict__ bandN, const double* __restrict__ L,
-                                                          const double* __restrict__ R, int* __restrict__ out) {
+// ms_stereo.py:5-27 for one block per wavefront: per band, sum|L^2 - R^2| < 0.8 sum|L^2 + R^2| with both sums rounded
+// exactly as np.sum rounds them (pairwise summation, restated as the static tree of mrc::ms_plan).  A LEAF is a run
+// of <= 128 lines: eight lanes hold NumPy's eight strided accumulators r[0..7], combine them in its fixed order
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) with three in-register exchanges and add the < 8 trailing elements one by one;
+// runs of fewer than 8 lines are plain left-to-right sums.  Eight leaves are in flight per wave; one lane then adds the
+// few internal nodes (bands of more than 128 lines) in tree order.
+__global__ __launch_bounds__(kWave) void ms_switch_kernel(int nBands, int nLeaves, int nInternal,
+                                                          const int* __restrict__ plan, const double* __restrict__ L,
+                                                          const double* __restrict__ R, int64_t blockStride,
+                                                          int* __restrict__ out) {
+    __shared__ double sumD[64], sumS[64];
+    const int lane = threadIdx.x, g = lane >> 3, j = lane & 7;
     const int64_t blk = blockIdx.x;
-    for (int b = threadIdx.x; b < nBands; b += kWave)
-        out[blk * nBands + b] = ms_switch_band(L + blk * nTotal, R + blk * nTotal, bandLo[b], bandN[b]);
+    const double* l = L + blk * blockStride;
+    const double* r = R + blk * blockStride;
+    auto dOf = [&](int k) { const double a = l[k], b = r[k]; return fabs(a * a - b * b); };
+    auto sOf = [&](int k) { const double a = l[k], b = r[k]; return fabs(a * a + b * b); };
+    for (int t0 = 0; t0 < nLeaves; t0 += 8) {
+        const int t = t0 + g;
+        const bool have = t < nLeaves;
+        const int lo = have ? plan[2 * t] : 0, n = have ? plan[2 * t + 1] : 8;
+        double d, sgm;
+        // the exchanges below need every lane; lanes without a leaf run a dummy 8-element leaf at line 0
+        if (n < 8) {
+            d = 0.; sgm = 0.;
+            for (int i = 0; i < n; ++i) { d += dOf(lo + i); sgm += sOf(lo + i); }
+            // (keep the DPP steps convergent for the whole wave)
+            (void)dpp_move<0xB1>(d);
+        } else {
+            d = dOf(lo + j); sgm = sOf(lo + j);
+            const int body = n - (n % 8);
+            for (int i = 8; i < body; i += 8) { d += dOf(lo + i + j); sgm += sOf(lo + i + j); }
+            d += dpp_move<0xB1>(d);   sgm += dpp_move<0xB1>(sgm);     // r0+r1, r2+r3, ...   (quad_perm [1,0,3,2])
+            d += dpp_move<0x4E>(d);   sgm += dpp_move<0x4E>(sgm);     // (r0+r1)+(r2+r3), ... (quad_perm [2,3,0,1])
+            d += dpp_move<0x141>(d);  sgm += dpp_move<0x141>(sgm);    // + the other quad     (row_half_mirror)
+            for (int i = body; i < n; ++i) { d += dOf(lo + i); sgm += sOf(lo + i); }
+        }
+        if (have && j == 0) { sumD[t] = d; sumS[t] = sgm; }
+    }
+    __syncthreads();
+    if (lane == 0) {
+        const int* inner = plan + 2 * nLeaves;
+        for (int q = 0; q < nInternal; ++q) {
+            sumD[nLeaves + q] = sumD[inner[2 * q]] + sumD[inner[2 * q + 1]];
+            sumS[nLeaves + q] = sumS[inner[2 * q]] + sumS[inner[2 * q + 1]];
+        }
+    }
+    __syncthreads();
+    if (lane < nBands) {
+        const int root = plan[2 * nLeaves + 2 * nInternal + lane];
+        out[blk * nBands + lane] = sumD[root] < 0.8 * sumS[root] ? 1 : 0;
+    }
 }
 
 }  // namespace
@@ -204,12 +250,13 @@ hipError_t launch_mdct(const DevShape& S, int64_t nFrames, const void* chL, cons
         return launch_mdct_long(S, nFrames, chL, chR, fmt, stride, offsets, lines, oscale, st);
     const int nsig = chR ? 4 : 1;
     size_t lds = (size_t)(2 * S.N) * sizeof(double);
-    if (fmt == kSampleI16)
-        hipLaunchKernelGGL(mdct_kernel<short>, dim3((unsigned)(nFrames * nsig)), dim3(kThreads), lds, st, S, nsig,
-                           (const short*)chL, (const short*)chR, stride, offsets, applyWindow ? S.win : nullptr, lines, oscale);
-    else
-        hipLaunchKernelGGL(mdct_kernel<double>, dim3((unsigned)(nFrames * nsig)), dim3(kThreads), lds, st, S, nsig,
-                           (const double*)chL, (const double*)chR, stride, offsets, applyWindow ? S.win : nullptr, lines, oscale);
+    // a short block (N <= 256: 64 complex FFT points) is one wavefront's work; longer ones take four
+#define MRC_MDCT_LAUNCH(TY, THREADS)                                                                                  \
+    hipLaunchKernelGGL((mdct_kernel<TY, THREADS>), dim3((unsigned)(nFrames * nsig)), dim3(THREADS), lds, st, S, nsig,   \
+                       (const TY*)chL, (const TY*)chR, stride, offsets, applyWindow ? S.win : nullptr, lines, oscale)
+    if (fmt == kSampleI16) { if (S.N <= 256) MRC_MDCT_LAUNCH(short, 64); else MRC_MDCT_LAUNCH(short, 256); }
+    else { if (S.N <= 256) MRC_MDCT_LAUNCH(double, 64); else MRC_MDCT_LAUNCH(double, 256); }
+#undef MRC_MDCT_LAUNCH
     return hipGetLastError();
 }
 
@@ -281,11 +328,11 @@ hipError_t launch_stereo_masking(int64_t n, const double* mid, const double* sid
     return hipGetLastError();
 }
 
-hipError_t launch_ms_switch(int64_t nBlocks, int nBands, int nTotal, const int* bandLo, const int* bandN,
-                            const double* L, const double* R, int* out, hipStream_t st) {
+hipError_t launch_ms_switch(int64_t nBlocks, int nBands, int nLeaves, int nInternal, const int* plan, const double* L,
+                            const double* R, int64_t blockStride, int* out, hipStream_t st) {
     if (nBlocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(ms_switch_kernel, dim3((unsigned)nBlocks), dim3(kWave), 0, st, nBands, nTotal, bandLo, bandN, L,
-                       R, out);
+    hipLaunchKernelGGL(ms_switch_kernel, dim3((unsigned)nBlocks), dim3(kWave), 0, st, nBands, nLeaves, nInternal, plan, L, R,
+                       blockStride, out);
     return hipGetLastError();
 }
 

@@ -1,6 +1,7 @@
 // Back end of the encode path on gfx950, after the lines and SMRs exist:
-//   band_stats_kernel   ms_stereo.py:5-27 (per-band M/S decision, joint only) and the per-band max |X| that the
-//                       scale factors need (codecThem.py:346) -- one wavefront per frame
+//   band_stats_kernel   the per-band max |X| that the scale factors need (codecThem.py:346) for the stage entry points
+//                       (the full path gets them from smr_kernel); the M/S decision (ms_stereo.py:5-27) is
+//                       ms_switch_kernel in mrc_kernels.hip
 //   bitalloc_kernel     ms_stereo.py:70-81 (SMR select) + budgets (codecThem.py:299-308, 381-396) +
 //                       bitalloc.py:106-155 -- ONE LANE PER FRAME: the greedy loop is serial per frame, so 64
 //                       frames share a wavefront and each lane scans its own <= 64 running SMRs in LDS
@@ -36,8 +37,6 @@ __global__ __launch_bounds__(kWave) void band_stats_kernel(DevShape S, int joint
         for (int k = lane; k < M; k += kWave)
             atomicMax(&peakBits[s * nb + S.bandOfLine[k]],
                       (unsigned long long)__double_as_longlong(fabs(X[s * M + k])));
-    if (joint && lane < nb)                              // on the UNSCALED L/R lines (codecThem.py:436)
-        msSwitch[f * nb + lane] = ms_switch_band(X, X + M, S.bandLo[lane], S.bandN[lane]);
     __syncthreads();
     for (int i = lane; i < (wantPeaks ? nsig * nb : 0); i += kWave)
         bandPeak[f * nsig * nb + i] = __longlong_as_double((long long)peakBits[i]);
@@ -49,7 +48,7 @@ __global__ __launch_bounds__(kWave) void band_stats_kernel(DevShape S, int joint
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double bitalloc_lane(double* __restrict__ run, unsigned char* __restrict__ bits,
                                                 const int* __restrict__ nLines, int nTot, int maxMantBits,
-                                                double budget, int lane, bool active) {
+                                                double budget, int lane, bool active, int ld = kWave) {
     double left = budget;
     int retired = 0;
     // every iteration grants (<= maxMantBits-1 times per band) or retires (<= nTot times): the loop ends by
@@ -61,23 +60,23 @@ __device__ __forceinline__ double bitalloc_lane(double* __restrict__ run, unsign
             double best = run[lane];
             int idx = 0;
             for (int b = 1; b < nTot; ++b) {
-                const double v = run[b * kWave + lane];
+                const double v = run[b * ld + lane];
                 if (v > best) { best = v; idx = b; }            // np.argmax: first maximum wins
             }
-            const int have = bits[idx * kWave + lane];
+            const int have = bits[idx * ld + lane];
             const int n = nLines[idx];
             if (have < maxMantBits && (double)n <= left) {
                 if (have == 0) {
-                    bits[idx * kWave + lane] = 2;
+                    bits[idx * ld + lane] = 2;
                     left -= (double)(2 * n);
-                    run[idx * kWave + lane] = best - 12.0;
+                    run[idx * ld + lane] = best - 12.0;
                 } else {
-                    bits[idx * kWave + lane] = (unsigned char)(have + 1);
+                    bits[idx * ld + lane] = (unsigned char)(have + 1);
                     left -= (double)n;
-                    run[idx * kWave + lane] = best - 6.0;
+                    run[idx * ld + lane] = best - 6.0;
                 }
             } else {
-                run[idx * kWave + lane] = -99999999999999999.0;
+                run[idx * ld + lane] = -99999999999999999.0;
                 if (++retired == nTot) live = false;
             }
             if (!(left > 0) || --guard <= 0) live = false;
@@ -86,42 +85,46 @@ __device__ __forceinline__ double bitalloc_lane(double* __restrict__ run, unsign
     return left;
 }
 
-__global__ __launch_bounds__(kWave) void bitalloc_kernel(DevShape S, int joint, int64_t nFrames,
+// The greedy loop is a chain of dependent LDS reads: a wave waits most of the time.  With few frames per launch the
+// frames are therefore spread over MORE waves (fpw <= 64 frames per wave, the other lanes idle): 65 536 frames at 64
+// per wave are one wave per SIMD and pure latency; at 8 per wave the same SIMD interleaves eight such chains.
+__global__ __launch_bounds__(kWave) void bitalloc_kernel(DevShape S, int joint, int64_t nFrames, int fpw,
                                                          const double* __restrict__ smr,
                                                          const int* __restrict__ msSwitch,
                                                          const int* __restrict__ resIn, int* __restrict__ bitAlloc,
                                                          int* __restrict__ resOut) {
-    extern __shared__ double lds[];                     // run[nTot][64] doubles, then bits[nTot][64] bytes, nLines[nTot]
+    extern __shared__ double lds[];                     // run[nTot][fpw] doubles, then bits[nTot][fpw] bytes, nLines[nTot]
     const int lane = threadIdx.x;
     const int nb = S.nBands, nsig = joint ? 4 : 1, nstream = joint ? 2 : 1;
     const int nTot = nstream * nb;
     double* run = lds;
-    unsigned char* bits = reinterpret_cast<unsigned char*>(lds + nTot * kWave);
-    int* nl = reinterpret_cast<int*>(bits + nTot * kWave);
-    const int64_t f0 = (int64_t)blockIdx.x * kWave;
-    const int64_t f = f0 + lane;
-    const bool active = f < nFrames;
+    unsigned char* bits = reinterpret_cast<unsigned char*>(lds + nTot * fpw);
+    int* nl = reinterpret_cast<int*>(bits + ((nTot * fpw + 3) & ~3));
+    const int64_t f = (int64_t)blockIdx.x * fpw + lane;
+    const bool active = lane < fpw && f < nFrames;
     for (int i = lane; i < nTot; i += kWave) nl[i] = S.bandN[i % nb];
     // stream 0 = Mid-or-Left, stream 1 = Side-or-Right (ms_stereo.py:70-81, codecThem.py:485,524-551)
-    for (int i = 0; i < nTot; ++i) {
-        const int band = i % nb, strm = i / nb;
-        double v = 0.0;
-        if (active) {
-            const int sig = joint ? (msSwitch[f * nb + band] ? 2 + strm : strm) : 0;
-            v = smr[(f * nsig + sig) * nb + band];
+    if (lane < fpw) {
+        for (int i = 0; i < nTot; ++i) {
+            const int band = i % nb, strm = i / nb;
+            double v = 0.0;
+            if (active) {
+                const int sig = joint ? (msSwitch[f * nb + band] ? 2 + strm : strm) : 0;
+                v = smr[(f * nsig + sig) * nb + band];
+            }
+            run[i * fpw + lane] = v;
+            bits[i * fpw + lane] = 0;
         }
-        run[i * kWave + lane] = v;
-        bits[i * kWave + lane] = 0;
     }
     __syncthreads();
     const double r = (active && resIn) ? (double)resIn[f] : 0.0;
     double budget;
     if (joint) { budget = S.budgetJointPre + r; budget -= S.blkswA; budget -= S.blkswB; }   // codecThem.py:390-396
     else budget = S.budgetMono + r;                                                           // codecThem.py:308
-    const double left = bitalloc_lane(run, bits, nl, nTot, S.maxMantBits, budget, lane, active);
+    const double left = bitalloc_lane(run, bits, nl, nTot, S.maxMantBits, budget, lane, active, fpw);
     if (active) {
         resOut[f] = (int)left;                            // int(bitsLeft): truncation toward zero (bitalloc.py:155)
-        for (int i = 0; i < nTot; ++i) bitAlloc[f * nTot + i] = bits[i * kWave + lane];
+        for (int i = 0; i < nTot; ++i) bitAlloc[f * nTot + i] = bits[i * fpw + lane];
     }
 }
 
@@ -228,14 +231,21 @@ hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, con
                               hipEvent_t* ev /* null, or 2 events: after band_stats, after bitalloc */, hipStream_t st) {
     if (nFrames <= 0) return hipSuccess;
     const int nTot = (joint ? 2 : 1) * S.nBands;
-    // the per-band peaks come from smr_kernel on the full path; this kernel is then only the M/S decision (joint)
-    if (joint || !peaksReady)
-        hipLaunchKernelGGL(band_stats_kernel, dim3((unsigned)nFrames), dim3(kWave), 0, st, S, joint, peaksReady ? 0 : 1,
-                           lines, msSwitch, bandPeakWs);
+    // the per-band peaks come from smr_kernel on the full path; band_stats_kernel only serves the stage entry points
+    if (!peaksReady)
+        hipLaunchKernelGGL(band_stats_kernel, dim3((unsigned)nFrames), dim3(kWave), 0, st, S, joint, 1, lines, msSwitch,
+                           bandPeakWs);
+    if (joint) {                                         // on the UNSCALED L / R lines (codecThem.py:436)
+        hipError_t e = launch_ms_switch(nFrames, S.nBands, S.msLeaves, S.msInternal, S.msPlan, lines, lines + S.halfN,
+                                        4 * (int64_t)S.halfN, msSwitch, st);
+        if (e != hipSuccess) return e;
+    }
     if (ev) (void)hipEventRecord(ev[0], st);
-    const size_t lds = (size_t)nTot * kWave * (sizeof(double) + 1) + (size_t)nTot * sizeof(int);
-    hipLaunchKernelGGL(bitalloc_kernel, dim3((unsigned)((nFrames + kWave - 1) / kWave)), dim3(kWave), lds, st, S, joint,
-                       nFrames, smr, msSwitch, resIn, bitAlloc, resOut);
+    int fpw = kWave;                                     // frames per wave: aim at >= 8 waves per SIMD (1024 SIMDs)
+    while (fpw > 8 && nFrames / fpw < 8192) fpw >>= 1;
+    const size_t lds = (size_t)nTot * fpw * sizeof(double) + (((size_t)nTot * fpw + 3) & ~(size_t)3) + (size_t)nTot * sizeof(int);
+    hipLaunchKernelGGL(bitalloc_kernel, dim3((unsigned)((nFrames + fpw - 1) / fpw)), dim3(kWave), lds, st, S, joint,
+                       nFrames, fpw, smr, msSwitch, resIn, bitAlloc, resOut);
     if (ev) (void)hipEventRecord(ev[1], st);
     if (mantFmt == MRC_MANTISSA_I16)
         hipLaunchKernelGGL(quantize_kernel<unsigned short>, dim3((unsigned)(nFrames * (joint ? 2 : 1))), dim3(kWave), 0, st, S, joint,

@@ -81,29 +81,59 @@ __device__ __forceinline__ double exp2_poly(double f) {
     return fma(p, f, 1.0);
 }
 
-// 2^(s64*u/64) for the spreading loop, table driven: n = rint(s64*u) splits into k = n >> 6 (exponent),
-// j = n & 63 (entry of the 2^(j/64) table in LDS) and a remainder g = s64*u - n in [-1/2, 1/2] (exact, by fma)
-// whose 2^(g/64) = exp(g ln2/64) is the Taylor polynomial of degree 5 (remainder < 3.5e-17).  10 fp64 + 4 integer
-// instructions per pair; max relative error ~3e-16.  s64*u == 0 gives exactly 1 (a line inside +-1/2 Bark gets
-// exactly the masker's intensity).  Requires |s64*u| < 2^31 (here it is < 16000).
-constexpr int kExpTab = 64;
+// 2^(sT*u/T) for the spreading loop, table driven (T = kExpTab entries per octave, sT = slope in 1/T bit per Bark):
+// n = rint(sT*u) splits into k = n / T (exponent), j = n mod T (entry of the 2^(j/T) table in LDS) and a remainder
+// g = sT*u - n in [-1/2, 1/2] (exact, by fma) whose 2^(g/T) = exp(g ln2/T) is a Taylor polynomial (T = 64: degree 5,
+// remainder < 3.5e-17; T = 32: degree 6, remainder < 3.5e-18).  sT*u == 0 gives exactly 1 (a line inside +-1/2 Bark
+// gets exactly the masker's intensity).  Requires |sT*u| < 2^31 (here it is < 16000).
+// T = 32 is the default: 32 entries of 8 bytes fill the 64 LDS banks exactly once, so the per-lane lookups of a wave
+// never collide (different entries sit in different banks, equal entries broadcast), whereas 64 entries put j and
+// j + 32 on one bank pair -- with the lanes' indices spread at random that was a 2-4 way conflict on every lookup and
+// 43 % of all LDS cycles of the kernel (profiles/r01_v17_sq_counters.json).  One more fma pays for it.
+#ifndef MRC_EXP_TAB
+#define MRC_EXP_TAB 32
+#endif
+constexpr int kExpTab = MRC_EXP_TAB;
+constexpr int kExpTabShift = MRC_EXP_TAB == 32 ? 5 : 6;
+constexpr double kExpTabD = (double)MRC_EXP_TAB;
+static_assert(MRC_EXP_TAB == 32 || MRC_EXP_TAB == 64, "2^x table: 32 or 64 entries per octave");
 // an SPL reaches its -30 dB floor at an intensity of 10^-12.6 (psychoac.py:8-12); above this guard it does not
 constexpr double kSplFloorGuard = 1e-12;
-__device__ __forceinline__ double exp2_tab64(double s64, double u, const double* __restrict__ tab) {
+__device__ __forceinline__ double exp2_tab64(double sT, double u, const double* __restrict__ tab) {
     const double shifter = 0x1.8p52;
-    const double tt = fma(s64, u, shifter);
+    const double tt = fma(sT, u, shifter);
     const double r = tt - shifter;
-    const double g = fma(s64, u, -r);
+    const double g = fma(sT, u, -r);
     const int n = __double2loint(tt);
+#if MRC_EXP_TAB == 32
+    double p = fma(0x1.430912f86c787p-43, g, 0x1.5d87fe78a6731p-35);
+    p = fma(p, g, 0x1.3b2ab6fba4e77p-27);
+    p = fma(p, g, 0x1.c6b08d704a0c0p-20);
+    p = fma(p, g, 0x1.ebfbdff82c58fp-13);
+    p = fma(p, g, 0x1.62e42fefa39efp-6);
+#else
     double p = fma(0x1.5d87fe78a6731p-40, g, 0x1.3b2ab6fba4e77p-31);
     p = fma(p, g, 0x1.c6b08d704a0c0p-23);
     p = fma(p, g, 0x1.ebfbdff82c58fp-15);
     p = fma(p, g, 0x1.62e42fefa39efp-7);
+#endif
     p = fma(p, g, 1.0);
-    return ldexp(p * tab[n & (kExpTab - 1)], n >> 6);
+    return ldexp(p * tab[n & (kExpTab - 1)], n >> kExpTabShift);
 }
 
-// 2^(j/64), j = 0..63, correctly rounded
+// 2^(j/T), j = 0..T-1, correctly rounded
+#if MRC_EXP_TAB == 32
+__constant__ double kExp2Tab[kExpTab] = {
+    0x1.0000000000000p+0, 0x1.059b0d3158574p+0, 0x1.0b5586cf9890fp+0, 0x1.11301d0125b51p+0,
+    0x1.172b83c7d517bp+0, 0x1.1d4873168b9aap+0, 0x1.2387a6e756238p+0, 0x1.29e9df51fdee1p+0,
+    0x1.306fe0a31b715p+0, 0x1.371a7373aa9cbp+0, 0x1.3dea64c123422p+0, 0x1.44e086061892dp+0,
+    0x1.4bfdad5362a27p+0, 0x1.5342b569d4f82p+0, 0x1.5ab07dd485429p+0, 0x1.6247eb03a5585p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.71f75e8ec5f74p+0, 0x1.7a11473eb0187p+0, 0x1.82589994cce13p+0,
+    0x1.8ace5422aa0dbp+0, 0x1.93737b0cdc5e5p+0, 0x1.9c49182a3f090p+0, 0x1.a5503b23e255dp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b7f76f2fb5e47p+0, 0x1.c199bdd85529cp+0, 0x1.cb720dcef9069p+0,
+    0x1.d5818dcfba487p+0, 0x1.dfc97337b9b5fp+0, 0x1.ea4afa2a490dap+0, 0x1.f50765b6e4540p+0
+};
+#else
 __constant__ double kExp2Tab[kExpTab] = {
     0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
     0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
@@ -120,7 +150,9 @@ __constant__ double kExp2Tab[kExpTab] = {
     0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
     0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
     0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
-    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0
+};
+#endif
 
 // 2^(hi + lo), |lo| << 1
 __device__ __forceinline__ double exp2_dd(double hi, double lo) {
@@ -213,7 +245,7 @@ __device__ __forceinline__ double far_group(const double* __restrict__ mt, int n
     for (int m = lane; m < nFar; m += kWave) {
         const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
         double term = I * exp2_tab64(sl, cq - zm, e2tab);                   // cq - zm > 0 for m < nFar
-        const double da = (sl - slMid) * (0.6931471805599453094 / 64.0);   // slope offset in nats per Bark
+        const double da = (sl - slMid) * (0.6931471805599453094 / kExpTabD);   // slope offset in nats per Bark
 #pragma unroll
         for (int j = 0; j <= J; ++j) {
             B[j] += term;
@@ -327,8 +359,8 @@ __device__ unsigned long long gPhaseCycles[16];
 #define MRC_PROFILE_SKIP 0                       // 1 far field, 2 direct pairs, 4 partial pairs, 8 chunk tail
 #endif
 
-template <bool EXACT, class SampleT>
-__global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, int nsig, const SampleT* __restrict__ chL,
+template <bool EXACT, class SampleT, int NT>
+__global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsig, const SampleT* __restrict__ chL,
                                                        const SampleT* __restrict__ chR, int64_t stride,
                                                        const int64_t* __restrict__ offsets,
                                                        const double* __restrict__ lines,
@@ -336,7 +368,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                                                        double* __restrict__ thresh, double* __restrict__ bandPeak,
                                                        SmrLds lay) {
     extern __shared__ double smem[];
-    __shared__ int waveCnt[kThreads / kWave];
+    __shared__ int waveCnt[NT / kWave];
     __shared__ unsigned long long bandKey[kMaxBands];   // per-band running max of the excess (order-preserving key)
     __shared__ unsigned long long slopeKey[2];          // min / max upper slope over the frame's maskers (keys)
     __shared__ unsigned long long peakKey[kMaxBands];   // per-band max |X| (the bit pattern of |x| orders like |x|)
@@ -382,11 +414,11 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     // (even, odd) sample pairs come as ONE load each when the block starts at an even sample of an aligned channel
     const bool pairAligned = !(off & 1) && !(reinterpret_cast<uintptr_t>(chL) & (2 * sizeof(SampleT) - 1)) &&
                              (!chR || !(reinterpret_cast<uintptr_t>(chR) & (2 * sizeof(SampleT) - 1)));
-    for (int n0 = tid; n0 < H; n0 += kThreads * kPre) {
+    for (int n0 = tid; n0 < H; n0 += NT * kPre) {
         double e[kPre], o[kPre], he[kPre], ho[kPre];
 #pragma unroll
         for (int u = 0; u < kPre; ++u) {
-            const int n = min(n0 + u * kThreads, H - 1);
+            const int n = min(n0 + u * NT, H - 1);
             const double2 eo = load_signal_pair(chL, chR, off + 2 * n, sig, pairAligned);
             e[u] = eo.x;
             o[u] = eo.y;
@@ -395,7 +427,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
         }
 #pragma unroll
         for (int u = 0; u < kPre; ++u) {
-            const int n = n0 + u * kThreads;
+            const int n = n0 + u * NT;
             if (n < H) A[n] = make_double2(e[u] * he[u], o[u] * ho[u]);
         }
     }
@@ -407,8 +439,8 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     double zbPre[kPre], logPre = 0.0, e2Pre = 0.0;
 #pragma unroll
     for (int u = 0; u < kPre; ++u) {
-        wnPre[u] = S.wN[min(tid + u * kThreads, last - 1)];
-        zbPre[u] = EXACT ? 0.0 : S.zb[min(tid + u * kThreads, M - 1)];
+        wnPre[u] = S.wN[min(tid + u * NT, last - 1)];
+        zbPre[u] = EXACT ? 0.0 : S.zb[min(tid + u * NT, M - 1)];
     }
     if (!EXACT) {
         logPre = kLogTabDev.v[tid & (kLogTabEntries * 4 - 1)];
@@ -417,23 +449,23 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     double2* T;
     if (lay.twOff >= 0) {
         double2* Wq = reinterpret_cast<double2*>(smem + lay.twOff);
-        for (int t = tid; t < H / 4; t += kThreads) Wq[t] = S.wH[t];
+        for (int t = tid; t < H / 4; t += NT) Wq[t] = S.wH[t];
         __syncthreads();
         MRC_PHASE(0); MRC_STOP(0);
-        T = fft_lds_pow2(A, B, H, S.radH, S.nRadH, TwQuarter{Wq, H / 4 - 1, 31 - __clz(H / 4)}, tid);
+        T = fft_lds_pow2<NT>(A, B, H, S.radH, S.nRadH, TwQuarter{Wq, H / 4 - 1, 31 - __clz(H / 4)}, tid);
     } else {
         __syncthreads();
         MRC_PHASE(0); MRC_STOP(0);
-        T = fft_lds(A, B, H, S.radH, S.nRadH, S.wH, tid);
+        T = fft_lds_global<NT>(A, B, H, S.radH, S.nRadH, S.wH, tid);
     }
     MRC_PHASE(1); MRC_STOP(1);
-    for (int k0 = tid; k0 < last; k0 += kThreads * kPre) {
+    for (int k0 = tid; k0 < last; k0 += NT * kPre) {
         double2 wn[kPre];
 #pragma unroll
-        for (int u = 0; u < kPre; ++u) wn[u] = (k0 == tid) ? wnPre[u] : S.wN[min(k0 + u * kThreads, last - 1)];
+        for (int u = 0; u < kPre; ++u) wn[u] = (k0 == tid) ? wnPre[u] : S.wN[min(k0 + u * NT, last - 1)];
 #pragma unroll
         for (int u = 0; u < kPre; ++u) {
-            const int k = k0 + u * kThreads;
+            const int k = k0 + u * NT;
             if (k < last) {
                 double2 zk = T[k];
                 double2 zc = T[(H - k) % H];
@@ -454,8 +486,8 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
         double* zw = smem + lay.zbOff;
 #pragma unroll
         for (int u = 0; u < kPre; ++u)
-            if (tid + u * kThreads < M) zw[tid + u * kThreads] = zbPre[u];
-        for (int k = tid + kPre * kThreads; k < M; k += kThreads) zw[k] = S.zb[k];
+            if (tid + u * NT < M) zw[tid + u * NT] = zbPre[u];
+        for (int k = tid + kPre * NT; k < M; k += NT) zw[k] = S.zb[k];
         if (tid < kLogTabEntries * 4) smem[lay.logOff + tid] = logPre;
         if (tid < kExpTab) smem[2 * H - kExpTab + tid] = e2Pre;
         if (tid < kMaxBands) ratioKey[tid] = 0ull;
@@ -467,7 +499,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     //   fast : {I = 10^((level-15-96)/10), Bark z, upper slope in bits/Bark, I * 2^(b z)}
     double* mt = smem;
     const int nCand = last - 2;
-    const int per = (nCand + kThreads - 1) / kThreads;
+    const int per = (nCand + NT - 1) / NT;
     const int p0 = 1 + tid * per;
     const int p1 = min(p0 + per, last - 1);
     int mine = 0;
@@ -476,7 +508,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     if (lane == kWave - 1) waveCnt[wave] = incl;
     __syncthreads();
     int before = incl - mine, nPeaks = 0;
-    for (int w = 0; w < kThreads / kWave; ++w) {
+    for (int w = 0; w < NT / kWave; ++w) {
         const int c = waveCnt[w];
         if (w < wave) before += c;
         nPeaks += c;
@@ -486,11 +518,11 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     for (int p = p0; p < p1; ++p)
         if (xi[p] > xi[p - 1] && xi[p] > xi[p + 1]) pkBin[before++] = (short)p;
     if (!EXACT)
-        for (int k = tid; k <= M; k += kThreads) { cntArr[k] = 0; nUpArr[k] = 0; }
+        for (int k = tid; k <= M; k += NT) { cntArr[k] = 0; nUpArr[k] = 0; }
     __syncthreads();
     MRC_PHASE(3); MRC_STOP(3);
     double slLo = 1e300, slHi = -1e300;                 // this thread's maskers: range of the upper slope
-    for (int mi = tid; mi < nPeaks; mi += kThreads) {
+    for (int mi = tid; mi < nPeaks; mi += NT) {
         const int p = pkBin[mi];
         const int before = mi;
         double x0 = xi[p - 1], x1 = xi[p], x2 = xi[p + 1];
@@ -517,7 +549,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                 const double ph = kLowHi * zm;
                 const double pl = fma(kLowHi, zm, -ph) + kLowLo * zm;
                 e[0] = I;
-                e[2] = (((-27 + boost) * 0.1) * kLog2Of10) * 64.0;         // upper slope, 1/64 bit per Bark
+                e[2] = (((-27 + boost) * 0.1) * kLog2Of10) * kExpTabD;     // upper slope, 1/T bit per Bark
                 slLo = fmin(slLo, e[2]);
                 slHi = fmax(slHi, e[2]);
                 e[3] = I * exp2_dd(ph, pl);
@@ -555,11 +587,11 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     const double* X = lines + (int64_t)unit * M;
 
     if (EXACT) {
-        for (int base = 0; base < M; base += kThreads * kLinesPerThread) {
+        for (int base = 0; base < M; base += NT * kLinesPerThread) {
             double z[kLinesPerThread], tot[kLinesPerThread];
 #pragma unroll
             for (int j = 0; j < kLinesPerThread; ++j) {
-                int k = base + tid + j * kThreads;
+                int k = base + tid + j * NT;
                 bool ok = k < M;
                 z[j] = ok ? S.zb[k] : 0.0;
                 tot[j] = ok ? S.quiet[k] : 0.0;
@@ -580,7 +612,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
             }
 #pragma unroll
             for (int j = 0; j < kLinesPerThread; ++j) {
-                int k = base + tid + j * kThreads;
+                int k = base + tid + j * NT;
                 if (k < M) {
                     double thr = spl_db(tot[j]);                                 // psychoac.py:173
                     if (thresh) thresh[(int64_t)unit * M + k] = thr;
@@ -595,7 +627,9 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     } else {
         // suffix sums of the lower-side constants: sc[m] = sum_{j >= m} I_j 2^(b z_j), sc[nPeaks] = 0
         double* sc = xi;                                // xi is dead (all peak reads happened before the barrier)
-        if (wave == 0) {
+        // four independent scans, dealt to the workgroup's waves (4 waves: one each; 2 waves: two each)
+        for (int task = wave; task < 4; task += NT / kWave) {
+        if (task == 0) {
             constexpr int kSeg = 8;                     // kWave * kSeg = 512 >= max number of peaks (N/4)
             double loc[kSeg];
             double run = 0.0;
@@ -620,7 +654,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                 if (m < nPeaks) sc[m] = loc[i] + higher;
             }
             if (lane == 0) sc[nPeaks] = 0.0;
-        } else if (wave == 1 % (kThreads / kWave)) {
+        } else if (task == 1) {
             // pi[m] = I_0 + ... + I_{m-1} in double-double: the in-band sum of a line is a DIFFERENCE of two
             // prefix sums, and with ~106 bits the difference is exact to far below one ulp of the result even
             // when a loud masker sits in the prefix (dynamic range of I within a frame < 2^50)
@@ -653,7 +687,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
             // waves 2 and 3 -- per-line masker counts: inclusive prefix sums of the two histograms the table build left
             // (cnt[k] = maskers with fl(z_k - z_m) >= -1/2, nUp[k] = maskers with fl(z_k - z_m) > 1/2), one array per
             // wave, so the three scans of this phase run side by side and share one barrier
-            unsigned short* arr = (wave == 2) ? cntArr : nUpArr;
+            unsigned short* arr = (task == 2) ? cntArr : nUpArr;
             const int per2 = (M + kWave) / kWave;                            // entries per lane, covers 0..M
             const int k0 = lane * per2, k1 = min(k0 + per2, M + 1);
             int sum = 0;
@@ -663,6 +697,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
                 run += arr[k];
                 arr[k] = (unsigned short)run;
             }
+        }
         }
         __syncthreads();
         MRC_PHASE(5); MRC_STOP(5);
@@ -674,7 +709,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
         // (lower slope, served by the suffix sums).  Wave-uniform bounds over the chunk turn that into
         // three scalar loops.
         const int nChunks = (M + kWave - 1) / kWave;
-        const int nWaves = kThreads / kWave;
+        const int nWaves = NT / kWave;
         // the per-line constants of the NEXT chunk are loaded while this one is computed (loop-carried, so the
         // global-load latency is never exposed between the loops of a chunk)
         struct LineConst { double z, quiet, lowE, x; int bnd; };
@@ -686,7 +721,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
         };
         __builtin_amdgcn_s_setprio(0);
         const double slMid = 0.5 * (order_value(slopeKey[0]) + order_value(slopeKey[1]));
-        const double spreadHalf = 0.5 * (order_value(slopeKey[1]) - order_value(slopeKey[0])) * (0.6931471805599453094 / 64.0);
+        const double spreadHalf = 0.5 * (order_value(slopeKey[1]) - order_value(slopeKey[0])) * (0.6931471805599453094 / kExpTabD);
         // Rounds of up to four chunks per wave.  Pass 1 evaluates the FAR FIELD of the round's chunks -- the only part
         // that needs a large register tile (the expansion coefficients) -- and keeps one value per line; pass 2 does
         // the near maskers, the in-band and lower-side sums and the SPL conversions with that value added in.
@@ -848,7 +883,7 @@ __global__ __launch_bounds__(kThreads) MRC_SMR_OCC void smr_kernel(DevShape S, i
     }
     __syncthreads();
     MRC_PHASE(11);
-    for (int bnd = tid; bnd < S.nBands; bnd += kThreads) {
+    for (int bnd = tid; bnd < S.nBands; bnd += NT) {
         double v = bandKey[bnd] ? order_value(bandKey[bnd]) : -1e300;              // lines on the SPL floor / EXACT
         if (!EXACT && ratioKey[bnd]) {
             const double q = __longlong_as_double((long long)ratioKey[bnd]);
@@ -905,12 +940,15 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
         else { total += total & 1; lay.twOff = total; total += H / 2; }
     }
     const size_t lds = (size_t)total * sizeof(double);
-    const dim3 grid((unsigned)(nFrames * nsig)), block(kThreads);
-#define MRC_SMR_LAUNCH(EX, TY)                                                                                       \
-    hipLaunchKernelGGL((smr_kernel<EX, TY>), grid, block, lds, st, S, nsig, (const TY*)chL, (const TY*)chR, stride,  \
-                       offsets, lines, oscale, smr, thresh, bandPeak, lay)
-    if (fmt == kSampleI16) { if (exactSpread) MRC_SMR_LAUNCH(true, short); else MRC_SMR_LAUNCH(false, short); }
-    else { if (exactSpread) MRC_SMR_LAUNCH(true, double); else MRC_SMR_LAUNCH(false, double); }
+    // blocks of up to 128 lines (two 64-line chunks) run as two-wave workgroups: no idle waves holding CU wave slots
+    const dim3 grid((unsigned)(nFrames * nsig));
+#define MRC_SMR_LAUNCH(EX, TY, THREADS)                                                                              \
+    hipLaunchKernelGGL((smr_kernel<EX, TY, THREADS>), grid, dim3(THREADS), lds, st, S, nsig, (const TY*)chL,         \
+                       (const TY*)chR, stride, offsets, lines, oscale, smr, thresh, bandPeak, lay)
+#define MRC_SMR_PICK(EX, TY) do { if (M <= 2 * kWave) MRC_SMR_LAUNCH(EX, TY, 128); else MRC_SMR_LAUNCH(EX, TY, 256); } while (0)
+    if (fmt == kSampleI16) { if (exactSpread) MRC_SMR_PICK(true, short); else MRC_SMR_PICK(false, short); }
+    else { if (exactSpread) MRC_SMR_PICK(true, double); else MRC_SMR_PICK(false, double); }
+#undef MRC_SMR_PICK
 #undef MRC_SMR_LAUNCH
     return hipGetLastError();
 }

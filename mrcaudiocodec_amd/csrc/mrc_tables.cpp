@@ -130,6 +130,35 @@ bool band_table(const mrc_config& cfg, int a, int b, std::vector<int>* count) {
     return (*count)[nb - 1] >= 0;
 }
 
+void ms_plan(const std::vector<int>& bandLo, const std::vector<int>& bandN, std::vector<int>* plan, int* nLeaves,
+             int* nInternal) {
+    std::vector<std::pair<int, int>> leaves, inner;        // (lo, n); (left node, right node)
+    struct Rec {
+        std::vector<std::pair<int, int>>& leaves;
+        std::vector<std::pair<int, int>> pending;           // internal nodes as (left id, right id), ids fixed up below
+        // returns a node reference: >= 0 leaf index, < 0 -(internal index + 1)
+        int build(int lo, int n) {
+            if (n <= 128) { leaves.push_back({lo, n}); return (int)leaves.size() - 1; }
+            int n2 = n / 2;
+            n2 -= n2 % 8;
+            const int l = build(lo, n2);
+            const int r = build(lo + n2, n - n2);
+            pending.push_back({l, r});
+            return -(int)pending.size();
+        }
+    } rec{leaves, {}};
+    std::vector<int> roots;
+    for (size_t b = 0; b < bandN.size(); ++b) roots.push_back(rec.build(bandLo[b], bandN[b]));
+    const int nl = (int)leaves.size();
+    auto id = [nl](int ref) { return ref >= 0 ? ref : nl + (-ref - 1); };
+    plan->clear();
+    for (auto& lf : leaves) { plan->push_back(lf.first); plan->push_back(lf.second); }
+    for (auto& in : rec.pending) { plan->push_back(id(in.first)); plan->push_back(id(in.second)); }
+    for (int r : roots) plan->push_back(id(r));
+    *nLeaves = nl;
+    *nInternal = (int)rec.pending.size();
+}
+
 bool build_shape(const mrc_config& cfg, int a, int b, HostShape* out, std::string* err) {
     const int N = a + b;
     if (a <= 0 || b <= 0 || N % 4 != 0 || (b - a) % 4 != 0) {
@@ -226,11 +255,15 @@ bool build_shape(const mrc_config& cfg, int a, int b, HostShape* out, std::strin
     }
     S.linesPerHz = (double)N / (double)cfg.sample_rate;       // line index ~ f * N/fs - 1/2
 
+    std::vector<int> msPlanV;
+    ms_plan(out->bandLo, out->bandN, &msPlanV, &S.msLeaves, &S.msInternal);
+    if (S.msLeaves + S.msInternal > 64) { *err = "band table too fine for the M/S summation plan"; return false; }
+
     BlobWriter bw;
     size_t oWin = bw.put(win), oHann = bw.put(hann), oPre = bw.put(pre), oPost = bw.put(post);
     size_t oWQ = bw.put(wQ), oWH = bw.put(wH), oWN = bw.put(wN), oZb = bw.put(zb), oQuiet = bw.put(quiet), oLowE = bw.put(lowE);
     size_t oLo = bw.put(out->bandLo), oCnt = bw.put(out->bandN), oBol = bw.put(bandOfLine);
-    size_t oLoLine = bw.put(loLine), oHiLine = bw.put(hiLine);
+    size_t oLoLine = bw.put(loLine), oHiLine = bw.put(hiLine), oMsPlan = bw.put(msPlanV);
     void* blob = nullptr;
     if (hipMalloc(&blob, bw.bytes.size()) != hipSuccess) { *err = "hipMalloc(shape tables) failed"; return false; }
     if (hipMemcpy(blob, bw.bytes.data(), bw.bytes.size(), hipMemcpyHostToDevice) != hipSuccess) {
@@ -249,6 +282,7 @@ bool build_shape(const mrc_config& cfg, int a, int b, HostShape* out, std::strin
     S.bandOfLine = (const unsigned char*)(base + oBol);
     S.loLine = (const unsigned short*)(base + oLoLine);
     S.hiLine = (const unsigned short*)(base + oHiLine);
+    S.msPlan = (const int*)(base + oMsPlan);
     out->blob = blob;
     return true;
 }
