@@ -265,6 +265,8 @@ def main():
     ap.add_argument("--frames", type=int, default=1 << 17, help="mono frames per GPU per step")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--skip-extras", action="store_true", help="only the headline measurement (profiling runs)")
+    ap.add_argument("--only", choices=["stereo", "switch"], default=None,
+                    help="profiling runs: ONLY the timed loop of configs[2] / configs[3] (prints a short JSON line)")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -333,6 +335,26 @@ def main():
             acc += enc.h.kernel_ms()
         enc.h.set_timing(False)
         return acc / reps
+
+    if args.only:
+        # a profiler is watching: run nothing but this configuration's kernels
+        if args.only == "stereo":
+            Fs = F // 2
+            sl, sr = stream_slice(torch, device, "c3", 0, Fs)
+            el = timed_steps(lambda: enc.encode_long(sl, sr, Fs, mantissa16=True))
+            print(json.dumps({"only": "stereo", "frames": Fs, "ms_per_step": el / args.steps * 1e3,
+                              "Msamples_s": 2.0 * Fs * HOP * args.steps / el / 1e6}))
+        else:
+            (xs,) = stream_slice(torch, device, "c4", 0, F)
+            groups = {k: torch.tensor(v, dtype=torch.int64, device=device) for k, v in c4_shapes(F).items()}
+
+            def run_switched():
+                for (a, b), o in groups.items():
+                    enc.encode(a, b, xs, None, o.numel(), 0, o, mantissa16=True, offsets_checked=True)
+            el = timed_steps(run_switched)
+            print(json.dumps({"only": "switch", "hops": F, "ms_per_step": el / args.steps * 1e3,
+                              "Msamples_s": float(F) * HOP * args.steps / el / 1e6}))
+        return
 
     # ---- headline: configs[1], one global stream, rank r takes frames [first, first + F)
     first, count = shard_frames(world * F, world, rank)

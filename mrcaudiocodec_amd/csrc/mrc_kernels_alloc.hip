@@ -43,66 +43,106 @@ __global__ __launch_bounds__(kWave) void band_stats_kernel(DevShape S, int joint
 }
 
 // ------------------------------------------------------------------------------------------------
-// bit allocation (bitalloc.py:106-155), one lane per problem.  run[] / bits[] are this wave's LDS
-// slabs laid out [band][lane]: a lane's scan over bands is conflict-free and so is its indexed update.
+// bit allocation (bitalloc.py:106-155), one lane per problem.  run[] / bits[] are this wave's LDS slabs laid out
+// [band][lane]: a lane's scan over bands is conflict-free and so is its indexed update.
+// np.argmax over all bands every iteration is what the loop costs (it is bound by instruction issue), so the maximum is
+// kept in TWO LEVELS: bands are cut into groups of gs consecutive bands whose first maximum (value, index) sits in the
+// slabs gv / gi; an iteration compares the nG group maxima, updates one band and rescans only that band's group.
+// "First maximum wins" survives: strict > inside a group in band order, strict > across groups in group order.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double bitalloc_lane(double* __restrict__ run, unsigned char* __restrict__ bits,
-                                                const int* __restrict__ nLines, int nTot, int maxMantBits,
-                                                double budget, int lane, bool active, int ld = kWave) {
+struct AllocSlabs {
+    double* run;            // [nTot][ld]
+    double* gv;             // [nG][ld]
+    unsigned char* bits;    // [nTot][ld]
+    unsigned char* gi;      // [nG][ld]
+    int* nLines;            // [nTot]
+    int gs, nG;
+};
+__host__ __device__ inline int alloc_group_size(int nTot) { return nTot <= 16 ? 4 : nTot <= 32 ? 6 : 8; }
+__host__ __device__ inline size_t alloc_lds_bytes(int nTot, int ld) {
+    const int gs = alloc_group_size(nTot), nG = (nTot + gs - 1) / gs;
+    return (size_t)(nTot + nG) * ld * sizeof(double) + (((size_t)(nTot + nG) * ld + 3) & ~(size_t)3) + (size_t)nTot * sizeof(int);
+}
+__device__ __forceinline__ AllocSlabs alloc_slabs(double* lds, int nTot, int ld) {
+    AllocSlabs a;
+    a.gs = alloc_group_size(nTot);
+    a.nG = (nTot + a.gs - 1) / a.gs;
+    a.run = lds;
+    a.gv = lds + nTot * ld;
+    a.bits = reinterpret_cast<unsigned char*>(lds + (nTot + a.nG) * ld);
+    a.gi = a.bits + nTot * ld;
+    a.nLines = reinterpret_cast<int*>(a.bits + (((nTot + a.nG) * ld + 3) & ~3));
+    return a;
+}
+
+__device__ __forceinline__ void alloc_rescan(const AllocSlabs& A, int G, int nTot, int lane, int ld) {
+    const int b0 = G * A.gs, b1 = min(b0 + A.gs, nTot);
+    double v0 = A.run[b0 * ld + lane];
+    int i0 = b0;
+    for (int b = b0 + 1; b < b1; ++b) {
+        const double v = A.run[b * ld + lane];
+        if (v > v0) { v0 = v; i0 = b; }
+    }
+    A.gv[G * ld + lane] = v0;
+    A.gi[G * ld + lane] = (unsigned char)i0;
+}
+
+__device__ __forceinline__ double bitalloc_lane(const AllocSlabs& A, int nTot, int maxMantBits, double budget, int lane,
+                                                bool active, int ld = kWave) {
     double left = budget;
     int retired = 0;
     // every iteration grants (<= maxMantBits-1 times per band) or retires (<= nTot times): the loop ends by
     // itself; the counter only guards against spinning on NaN input
     int guard = (maxMantBits + 2) * nTot + 8;
     bool live = active && left > 0;
+    if (live)
+        for (int G = 0; G < A.nG; ++G) alloc_rescan(A, G, nTot, lane, ld);
     while (__any(live)) {
         if (live) {
-            double best = run[lane];
-            int idx = 0;
-            for (int b = 1; b < nTot; ++b) {
-                const double v = run[b * ld + lane];
-                if (v > best) { best = v; idx = b; }            // np.argmax: first maximum wins
+            double best = A.gv[lane];
+            int G = 0;
+            for (int g = 1; g < A.nG; ++g) {
+                const double v = A.gv[g * ld + lane];
+                if (v > best) { best = v; G = g; }              // np.argmax: first maximum wins
             }
-            const int have = bits[idx * ld + lane];
-            const int n = nLines[idx];
+            const int idx = A.gi[G * ld + lane];
+            const int have = A.bits[idx * ld + lane];
+            const int n = A.nLines[idx];
             if (have < maxMantBits && (double)n <= left) {
                 if (have == 0) {
-                    bits[idx * ld + lane] = 2;
+                    A.bits[idx * ld + lane] = 2;
                     left -= (double)(2 * n);
-                    run[idx * ld + lane] = best - 12.0;
+                    A.run[idx * ld + lane] = best - 12.0;
                 } else {
-                    bits[idx * ld + lane] = (unsigned char)(have + 1);
+                    A.bits[idx * ld + lane] = (unsigned char)(have + 1);
                     left -= (double)n;
-                    run[idx * ld + lane] = best - 6.0;
+                    A.run[idx * ld + lane] = best - 6.0;
                 }
             } else {
-                run[idx * ld + lane] = -99999999999999999.0;
+                A.run[idx * ld + lane] = -99999999999999999.0;
                 if (++retired == nTot) live = false;
             }
             if (!(left > 0) || --guard <= 0) live = false;
+            if (live) alloc_rescan(A, G, nTot, lane, ld);
         }
     }
     return left;
 }
 
-// The greedy loop is a chain of dependent LDS reads: a wave waits most of the time.  With few frames per launch the
-// frames are therefore spread over MORE waves (fpw <= 64 frames per wave, the other lanes idle): 65 536 frames at 64
-// per wave are one wave per SIMD and pure latency; at 8 per wave the same SIMD interleaves eight such chains.
+// fpw = frames per wave (<= 64; the launcher uses 64, see there).
 __global__ __launch_bounds__(kWave) void bitalloc_kernel(DevShape S, int joint, int64_t nFrames, int fpw,
                                                          const double* __restrict__ smr,
                                                          const int* __restrict__ msSwitch,
                                                          const int* __restrict__ resIn, int* __restrict__ bitAlloc,
                                                          int* __restrict__ resOut) {
-    extern __shared__ double lds[];                     // run[nTot][fpw] doubles, then bits[nTot][fpw] bytes, nLines[nTot]
+    extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const int nb = S.nBands, nsig = joint ? 4 : 1, nstream = joint ? 2 : 1;
     const int nTot = nstream * nb;
-    double* run = lds;
-    unsigned char* bits = reinterpret_cast<unsigned char*>(lds + nTot * fpw);
-    int* nl = reinterpret_cast<int*>(bits + ((nTot * fpw + 3) & ~3));
+    const AllocSlabs A = alloc_slabs(lds, nTot, fpw);
     const int64_t f = (int64_t)blockIdx.x * fpw + lane;
     const bool active = lane < fpw && f < nFrames;
-    for (int i = lane; i < nTot; i += kWave) nl[i] = S.bandN[i % nb];
+    for (int i = lane; i < nTot; i += kWave) A.nLines[i] = S.bandN[i % nb];
     // stream 0 = Mid-or-Left, stream 1 = Side-or-Right (ms_stereo.py:70-81, codecThem.py:485,524-551)
     if (lane < fpw) {
         for (int i = 0; i < nTot; ++i) {
@@ -112,8 +152,8 @@ __global__ __launch_bounds__(kWave) void bitalloc_kernel(DevShape S, int joint, 
                 const int sig = joint ? (msSwitch[f * nb + band] ? 2 + strm : strm) : 0;
                 v = smr[(f * nsig + sig) * nb + band];
             }
-            run[i * fpw + lane] = v;
-            bits[i * fpw + lane] = 0;
+            A.run[i * fpw + lane] = v;
+            A.bits[i * fpw + lane] = 0;
         }
     }
     __syncthreads();
@@ -121,10 +161,10 @@ __global__ __launch_bounds__(kWave) void bitalloc_kernel(DevShape S, int joint, 
     double budget;
     if (joint) { budget = S.budgetJointPre + r; budget -= S.blkswA; budget -= S.blkswB; }   // codecThem.py:390-396
     else budget = S.budgetMono + r;                                                           // codecThem.py:308
-    const double left = bitalloc_lane(run, bits, nl, nTot, S.maxMantBits, budget, lane, active, fpw);
+    const double left = bitalloc_lane(A, nTot, S.maxMantBits, budget, lane, active, fpw);
     if (active) {
         resOut[f] = (int)left;                            // int(bitsLeft): truncation toward zero (bitalloc.py:155)
-        for (int i = 0; i < nTot; ++i) bitAlloc[f * nTot + i] = bits[i * fpw + lane];
+        for (int i = 0; i < nTot; ++i) bitAlloc[f * nTot + i] = A.bits[i * fpw + lane];
     }
 }
 
@@ -136,23 +176,21 @@ __global__ __launch_bounds__(kWave) void bitalloc_cases_kernel(int64_t nCases, i
                                                                int* __restrict__ left, double* __restrict__ smrAfter) {
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
-    double* run = lds;
-    unsigned char* bits = reinterpret_cast<unsigned char*>(lds + nBands * kWave);
-    int* nl = reinterpret_cast<int*>(bits + nBands * kWave);
+    const AllocSlabs A = alloc_slabs(lds, nBands, kWave);
     const int64_t c = (int64_t)blockIdx.x * kWave + lane;
     const bool active = c < nCases;
-    for (int i = lane; i < nBands; i += kWave) nl[i] = nLines[i];
+    for (int i = lane; i < nBands; i += kWave) A.nLines[i] = nLines[i];
     for (int i = 0; i < nBands; ++i) {
-        run[i * kWave + lane] = active ? smr[c * nBands + i] : 0.0;
-        bits[i * kWave + lane] = 0;
+        A.run[i * kWave + lane] = active ? smr[c * nBands + i] : 0.0;
+        A.bits[i * kWave + lane] = 0;
     }
     __syncthreads();
-    const double l = bitalloc_lane(run, bits, nl, nBands, maxMantBits, active ? budget[c] : 0.0, lane, active);
+    const double l = bitalloc_lane(A, nBands, maxMantBits, active ? budget[c] : 0.0, lane, active);
     if (active) {
         left[c] = (int)l;
-        for (int i = 0; i < nBands; ++i) bitsOut[c * nBands + i] = bits[i * kWave + lane];
+        for (int i = 0; i < nBands; ++i) bitsOut[c * nBands + i] = A.bits[i * kWave + lane];
         // bitalloc.py:132-151 updates the caller's SMR array in place: the running values after the loop
-        if (smrAfter) for (int i = 0; i < nBands; ++i) smrAfter[c * nBands + i] = run[i * kWave + lane];
+        if (smrAfter) for (int i = 0; i < nBands; ++i) smrAfter[c * nBands + i] = A.run[i * kWave + lane];
     }
 }
 
@@ -241,9 +279,11 @@ hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, con
         if (e != hipSuccess) return e;
     }
     if (ev) (void)hipEventRecord(ev[0], st);
-    int fpw = kWave;                                     // frames per wave: aim at >= 8 waves per SIMD (1024 SIMDs)
-    while (fpw > 8 && nFrames / fpw < 8192) fpw >>= 1;
-    const size_t lds = (size_t)nTot * fpw * sizeof(double) + (((size_t)nTot * fpw + 3) & ~(size_t)3) + (size_t)nTot * sizeof(int);
+    // frames per wave.  Spreading a launch over more, emptier waves (fpw = 8 .. 32) was tried to hide the latency of the
+    // loop's dependent LDS reads: 2-3x SLOWER (mono 0.16 -> 0.30 ms, joint 0.52 -> 1.51 ms per 131 072 / 65 536 frames) --
+    // the loop is bound by instruction issue, not by latency, so full waves it is.
+    const int fpw = kWave;
+    const size_t lds = alloc_lds_bytes(nTot, fpw);
     hipLaunchKernelGGL(bitalloc_kernel, dim3((unsigned)((nFrames + fpw - 1) / fpw)), dim3(kWave), lds, st, S, joint,
                        nFrames, fpw, smr, msSwitch, resIn, bitAlloc, resOut);
     if (ev) (void)hipEventRecord(ev[1], st);
@@ -259,7 +299,7 @@ hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, con
 hipError_t launch_bitalloc_cases(int64_t nCases, int nBands, int maxMantBits, const int* nLines, const double* budget,
                                  const double* smr, int* bits, int* left, double* smrAfter, hipStream_t st) {
     if (nCases <= 0) return hipSuccess;
-    const size_t lds = (size_t)nBands * kWave * (sizeof(double) + 1) + (size_t)nBands * sizeof(int);
+    const size_t lds = alloc_lds_bytes(nBands, kWave);
     hipLaunchKernelGGL(bitalloc_cases_kernel, dim3((unsigned)((nCases + kWave - 1) / kWave)), dim3(kWave), lds, st,
                        nCases, nBands, maxMantBits, nLines, budget, smr, bits, left, smrAfter);
     return hipGetLastError();

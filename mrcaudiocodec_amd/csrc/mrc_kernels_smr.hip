@@ -86,12 +86,12 @@ __device__ __forceinline__ double exp2_poly(double f) {
 // g = sT*u - n in [-1/2, 1/2] (exact, by fma) whose 2^(g/T) = exp(g ln2/T) is a Taylor polynomial (T = 64: degree 5,
 // remainder < 3.5e-17; T = 32: degree 6, remainder < 3.5e-18).  sT*u == 0 gives exactly 1 (a line inside +-1/2 Bark
 // gets exactly the masker's intensity).  Requires |sT*u| < 2^31 (here it is < 16000).
-// T = 32 is the default: 32 entries of 8 bytes fill the 64 LDS banks exactly once, so the per-lane lookups of a wave
-// never collide (different entries sit in different banks, equal entries broadcast), whereas 64 entries put j and
-// j + 32 on one bank pair -- with the lanes' indices spread at random that was a 2-4 way conflict on every lookup and
-// 43 % of all LDS cycles of the kernel (profiles/r01_v17_sq_counters.json).  One more fma pays for it.
+// T = 64 is the default.  T = 32 (-DMRC_EXP_TAB=32) makes the lookups conflict-free -- 32 entries of 8 bytes fill the
+// 64 LDS banks exactly once, whereas 64 entries put j and j + 32 on one bank pair, a 2-4 way conflict on most lookups
+// and 43 % of the kernel's LDS cycles -- but measured 1.4 % SLOWER (5.02 vs 4.95 ms per 131 072 frames, round 2): the
+// LDS pipe is not what the waves wait for, and the extra fma is paid on every pair.
 #ifndef MRC_EXP_TAB
-#define MRC_EXP_TAB 32
+#define MRC_EXP_TAB 64
 #endif
 constexpr int kExpTab = MRC_EXP_TAB;
 constexpr int kExpTabShift = MRC_EXP_TAB == 32 ? 5 : 6;
