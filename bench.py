@@ -68,7 +68,7 @@ def algorithmic_bytes(joint, pcm16, mant16, a=1024, b=1024, nb=NB):
 
 
 KERNEL_NAMES = ["mdct", "smr", "band_stats", "bitalloc", "quantize"]
-KERNEL_LABEL = {"mdct": "mdct_long_kernel", "smr": "smr_kernel", "band_stats": "band_stats_kernel",
+KERNEL_LABEL = {"mdct": "mdct_long_kernel", "smr": "smr_kernel", "band_stats": "ms_switch_kernel",
                 "bitalloc": "bitalloc_kernel", "quantize": "quantize_kernel"}
 
 

@@ -260,7 +260,7 @@ int mrc_dev_smr(mrc_handle* h, int a, int b, int64_t n_frames, const double* ch_
     int rc = get_shape(h, a, b, &hs);
     if (rc) return rc;
     MRC_HIP(h, launch_smr(hs->dev, n_frames, ch_left, ch_right, kSampleF64, frame_stride, offsets, lines, overall_scale,
-                          smr, thresh, nullptr, h->exactSpread, pick_stream(h, stream)));
+                          smr, thresh, nullptr, nullptr, h->exactSpread, pick_stream(h, stream)));
     return MRC_OK;
 }
 
@@ -277,7 +277,7 @@ int mrc_dev_alloc_quant(mrc_handle* h, int a, int b, int64_t n_frames, int joint
     MRC_HIP(h, h->ws.peak.reserve(alloc_workspace_bytes(hs->dev, n_frames, joint)));
     MRC_HIP(h, launch_alloc_quant(hs->dev, n_frames, joint, lines, overall_scale, smr, reservoir_in, ms_switch,
                                   bit_alloc, scale_factor, mantissa, MRC_MANTISSA_I32, reservoir_out,
-                                  h->ws.peak.as<double>(), false, nullptr, pick_stream(h, stream)));
+                                  h->ws.peak.as<double>(), false, false, nullptr, pick_stream(h, stream)));
     return MRC_OK;
 }
 
@@ -341,17 +341,26 @@ int encode_core(mrc_handle* h, const DevShape& S, int64_t n, const void* chL, co
     if (timing) MRC_HIP(h, hipEventRecord(h->ev[0], st));
     MRC_HIP(h, launch_mdct(S, n, chL, chR, fmt, stride, offsets, true, lines, oscale, st));
     if (timing) MRC_HIP(h, hipEventRecord(h->ev[1], st));
-    MRC_HIP(h, launch_smr(S, n, chL, chR, fmt, stride, offsets, lines, oscale, smr, nullptr, ws.peak.as<double>(),
-                          h->exactSpread, st));
+    // the M/S decision needs only the L / R lines (codecThem.py:436); made BEFORE the SMRs, it tells smr_kernel which
+    // of the four signals' SMRs the encoder will use per band (ms_stereo.py:70-81) -- the others are not computed
+    if (joint)
+        MRC_HIP(h, launch_ms_switch(n, S.nBands, S.msLeaves, S.msInternal, S.msPlan, lines, lines + S.halfN,
+                                    4 * (int64_t)S.halfN, msSwitch, st));
     if (timing) MRC_HIP(h, hipEventRecord(h->ev[2], st));
+    MRC_HIP(h, launch_smr(S, n, chL, chR, fmt, stride, offsets, lines, oscale, smr, nullptr, ws.peak.as<double>(),
+                          joint ? msSwitch : nullptr, h->exactSpread, st));
+    if (timing) MRC_HIP(h, hipEventRecord(h->ev[3], st));
     MRC_HIP(h, launch_alloc_quant(S, n, joint, lines, oscale, smr, resIn, msSwitch, bitAlloc, scaleFactor, mantissa,
-                                  mantFmt, resOut, ws.peak.as<double>(), true, timing ? &h->ev[3] : nullptr, st));
+                                  mantFmt, resOut, ws.peak.as<double>(), true, true, timing ? &h->ev[3] : nullptr, st));
     if (timing) {
         MRC_HIP(h, hipEventRecord(h->ev[5], st));
         MRC_HIP(h, hipEventSynchronize(h->ev[5]));
+        // event order on the stream: 0 | mdct | 1 | ms_switch | 2 | smr | 3 (re-recorded: | nothing | 3) | bitalloc | 4 | quantize | 5
+        // reported order (mrc_get_kernel_ms): mdct, smr, ms_switch, bitalloc, quantize
+        static const int from[5] = {0, 2, 1, 3, 4}, to[5] = {1, 3, 2, 4, 5};
         for (int i = 0; i < 5; ++i) {
             float ms = 0.f;
-            MRC_HIP(h, hipEventElapsedTime(&ms, h->ev[i], h->ev[i + 1]));
+            MRC_HIP(h, hipEventElapsedTime(&ms, h->ev[from[i]], h->ev[to[i]]));
             h->kernelMs[i] = ms;
         }
         h->stageMs[0] = h->kernelMs[0];
@@ -765,7 +774,7 @@ int mrc_smr(mrc_handle* h, int64_t n, int a, int b, const double* blocks, const 
                                h->outA.as<int>(), h->stream));
     }
     MRC_HIP(h, launch_smr(S, n, h->inL.as<double>(), nullptr, kSampleF64, S.N, nullptr, h->outG.as<double>(), h->outA.as<int>(),
-                          h->outC.as<double>(), thresh ? h->outE.as<double>() : nullptr, nullptr, h->exactSpread,
+                          h->outC.as<double>(), thresh ? h->outE.as<double>() : nullptr, nullptr, nullptr, h->exactSpread,
                           h->stream));
     MRC_TRY(s.down(smr, h->outC, szSmr));
     if (thresh) MRC_TRY(s.down(thresh, h->outE, szLines));

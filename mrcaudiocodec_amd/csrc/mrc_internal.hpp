@@ -84,12 +84,14 @@ hipError_t launch_unscale(int64_t nBlocks, int halfN, const double* scaled, cons
 hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const void* chR, int fmt,
                       int64_t stride, const int64_t* offsets, const double* lines, const int* oscale,
                       double* smr, double* thresh, double* bandPeak /* [frames*signals][nBands] or null */,
+                      const int* msSwitch /* joint: [frames][nBands] -> only the SMRs the encoder uses are computed; null: all */,
                       bool exactSpread, hipStream_t st);
 hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, const double* lines,
                               const int* oscale, const double* smr, const int* resIn, int* msSwitch,
                               int* bitAlloc, int* scaleFactor, void* mantissa, int mantFmt /* MRC_MANTISSA_* */,
                               int* resOut, double* bandPeakWs,
                               bool peaksReady /* bandPeakWs already filled by launch_smr */,
+                              bool msReady /* msSwitch already filled (launch_ms_switch ran before launch_smr) */,
                               hipEvent_t* ev /* null or 2 events: after band_stats, after bitalloc */, hipStream_t st);
 hipError_t launch_pcm_to_float(int64_t n, const short* pcm, double* out, hipStream_t st);
 hipError_t launch_quantize_uniform(int64_t n, int nBits, const double* x, long long* out, hipStream_t st);

@@ -265,7 +265,7 @@ size_t alloc_workspace_bytes(const DevShape& S, int64_t nFrames, int joint) {
 
 hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, const double* lines, const int* oscale,
                               const double* smr, const int* resIn, int* msSwitch, int* bitAlloc, int* scaleFactor,
-                              void* mantissa, int mantFmt, int* resOut, double* bandPeakWs, bool peaksReady,
+                              void* mantissa, int mantFmt, int* resOut, double* bandPeakWs, bool peaksReady, bool msReady,
                               hipEvent_t* ev /* null, or 2 events: after band_stats, after bitalloc */, hipStream_t st) {
     if (nFrames <= 0) return hipSuccess;
     const int nTot = (joint ? 2 : 1) * S.nBands;
@@ -273,7 +273,7 @@ hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, con
     if (!peaksReady)
         hipLaunchKernelGGL(band_stats_kernel, dim3((unsigned)nFrames), dim3(kWave), 0, st, S, joint, 1, lines, msSwitch,
                            bandPeakWs);
-    if (joint) {                                         // on the UNSCALED L / R lines (codecThem.py:436)
+    if (joint && !msReady) {                             // on the UNSCALED L / R lines (codecThem.py:436)
         hipError_t e = launch_ms_switch(nFrames, S.nBands, S.msLeaves, S.msInternal, S.msPlan, lines, lines + S.halfN,
                                         4 * (int64_t)S.halfN, msSwitch, st);
         if (e != hipSuccess) return e;

@@ -43,13 +43,17 @@ __device__ __forceinline__ double order_value(unsigned long long k) {
     return __longlong_as_double((long long)b);
 }
 // far-field expansion (see the sweep): highest order, fewest maskers worth it, and for each supported order J the
-// largest |x| with |x|^(J+1)/(J+1)! e^|x| below 1e-17 (x = slope spread * half the Bark span of a group of lines)
+// largest |x| with |x|^(J+1)/(J+1)! e^|x| below 1e-15 (x = slope spread * half the Bark span of a group of lines)
 constexpr int kFarMaxOrder = 20;
 #ifndef MRC_FAR_MIN
 #define MRC_FAR_MIN 24
 #endif
 constexpr int kFarMinMaskers = MRC_FAR_MIN;
+#ifdef MRC_FAR_STRICT       // round-1 limits: truncated tail < 1e-17 of each term
 constexpr double kFarLimit8 = 0.052, kFarLimit12 = 0.27, kFarLimit16 = 0.68, kFarLimit20 = 1.0;
+#else                       // truncated tail < 1e-15 of each term (2 % faster: more chunks get by with a lower order; the
+constexpr double kFarLimit8 = 0.089, kFarLimit12 = 0.397, kFarLimit16 = 0.94, kFarLimit20 = 1.3;   // thresholds move < 1e-14 dB)
+#endif
 #ifndef MRC_FAR_MAX_ORDER                        // 20 costs 48 accumulator registers: spills around every chunk
 #define MRC_FAR_MAX_ORDER 16
 #endif
@@ -366,12 +370,13 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
                                                        const double* __restrict__ lines,
                                                        const int* __restrict__ oscale, double* __restrict__ smr,
                                                        double* __restrict__ thresh, double* __restrict__ bandPeak,
-                                                       SmrLds lay) {
+                                                       const int* __restrict__ msSwitch, SmrLds lay) {
     extern __shared__ double smem[];
     __shared__ int waveCnt[NT / kWave];
     __shared__ unsigned long long bandKey[kMaxBands];   // per-band running max of the excess (order-preserving key)
     __shared__ unsigned long long slopeKey[2];          // min / max upper slope over the frame's maskers (keys)
     __shared__ unsigned long long peakKey[kMaxBands];   // per-band max |X| (the bit pattern of |x| orders like |x|)
+    __shared__ unsigned char needBand[kMaxBands];       // joint blocks: does the encoder use THIS signal's SMR of the band?
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6;
     const int H = S.H, M = S.halfN;
@@ -403,6 +408,11 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
     if (tid < kMaxBands) bandKey[tid] = 0ull;           // below every key; visible after the first barrier
     if (tid < 2) slopeKey[tid] = tid ? 0ull : ~0ull;
     if (tid < kMaxBands) peakKey[tid] = 0ull;
+    // ms_stereo.py:70-81 (OverallSMRs) keeps, per band, either the L / R pair of SMRs or the M / S pair: the other two
+    // never reach the bit allocation.  With the switch known (it only needs the MDCT lines) the sweep below leaves out
+    // the 64-line chunks none of whose bands want this signal -- half of all (signal, band) pairs of a stereo frame.
+    if (tid < kMaxBands)
+        needBand[tid] = (!msSwitch || tid >= S.nBands) ? 1 : (((sig >= 2) == (msSwitch[f * S.nBands + tid] != 0)) ? 1 : 0);
     const double* zbS = smem + lay.zbOff;               // staged after the FFT (the area is FFT scratch / dead)
     const double* e2tab = smem + 2 * H - kExpTab;       // 2^(j/64): the tail of region A, behind the masker table
     // per-band max of (line intensity / masked threshold) as the bit pattern of a positive double; in front of e2tab
@@ -739,6 +749,7 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
             const int c = chunk_of(i0 + u);
             if (c >= nChunks) break;
             const int kc = min(c * kWave + lane, M - 1);
+            if (!__any(needBand[S.bandOfLine[kc]])) continue;                      // (see needBand)
             const int nFar = __builtin_amdgcn_readfirstlane((int)nUpArr[kc]);      // nUp of the chunk's first line
             if (nFar < kFarMinMaskers || (MRC_PROFILE_SKIP & 1)) continue;
             const double z = S.zb[kc];
@@ -792,6 +803,7 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
             const int kc = min(k, M - 1);
             const LineConst cur = nxt;
             nxt = load_consts(i + 1);
+            if (!__any(needBand[cur.bnd])) continue;                               // (see needBand)
             const double z = cur.z;
             // quiet threshold + far field (psychoac.py:155,166-168; the order of the additions is free, see above)
             double tot = cur.quiet + (u == 0 ? far0 : u == 1 ? far1 : u == 2 ? far2 : far3);
@@ -912,7 +924,7 @@ extern "C" int mrc_debug_phase_cycles(unsigned long long* out16, int reset) {
 
 hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const void* chR, int fmt, int64_t stride,
                       const int64_t* offsets, const double* lines, const int* oscale, double* smr, double* thresh,
-                      double* bandPeak, bool exactSpread, hipStream_t st) {
+                      double* bandPeak, const int* msSwitch, bool exactSpread, hipStream_t st) {
     if (nFrames <= 0) return hipSuccess;
     const int nsig = chR ? 4 : 1;
     // dynamic LDS (doubles): FFT ping-pong [4H] + intensity spectrum [peakLast + 1].  The staged tables go into
@@ -944,8 +956,11 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
     const dim3 grid((unsigned)(nFrames * nsig));
 #define MRC_SMR_LAUNCH(EX, TY, THREADS)                                                                              \
     hipLaunchKernelGGL((smr_kernel<EX, TY, THREADS>), grid, dim3(THREADS), lds, st, S, nsig, (const TY*)chL,         \
-                       (const TY*)chR, stride, offsets, lines, oscale, smr, thresh, bandPeak, lay)
-#define MRC_SMR_PICK(EX, TY) do { if (M <= 2 * kWave) MRC_SMR_LAUNCH(EX, TY, 128); else MRC_SMR_LAUNCH(EX, TY, 256); } while (0)
+                       (const TY*)chR, stride, offsets, lines, oscale, smr, thresh, bandPeak, msSwitch, lay)
+#ifndef MRC_SMR_THREADS                          // workgroup size for blocks of more than 128 lines
+#define MRC_SMR_THREADS 256
+#endif
+#define MRC_SMR_PICK(EX, TY) do { if (M <= 2 * kWave) MRC_SMR_LAUNCH(EX, TY, 128); else MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS); } while (0)
     if (fmt == kSampleI16) { if (exactSpread) MRC_SMR_PICK(true, short); else MRC_SMR_PICK(false, short); }
     else { if (exactSpread) MRC_SMR_PICK(true, double); else MRC_SMR_PICK(false, double); }
 #undef MRC_SMR_PICK
