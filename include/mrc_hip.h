@@ -322,6 +322,9 @@ int mrc_set_timing(mrc_handle* h, int enabled);
  * reference's own expression and pow() per (masker, line) instead of the factored fast form (default 0).
  * Both give the same integer outputs on the parity corpora; the exact form is ~8x slower. */
 #define MRC_OPT_EXACT_SPREAD 1
+/* MRC_OPT_SMR_ALL_BANDS = 1: in joint blocks compute the SMRs of all four signals in every band (default 0: only the
+ * pair the M/S switch selects per band, ms_stereo.py:70-81 -- the other pair never reaches the bit allocation). */
+#define MRC_OPT_SMR_ALL_BANDS 2
 int mrc_set_option(mrc_handle* h, int option, int value);
 int mrc_get_stage_ms(mrc_handle* h, double* ms /*[3]*/);
 /* ... and per kernel: ms[0..4] = MDCT, smr_kernel, band_stats_kernel (joint only, else ~0), bitalloc_kernel,

@@ -68,6 +68,7 @@ struct mrc_handle {
     DevBuf inL, inR, inAux, inAux2, inAux3, outA, outB, outC, outD, outE, outF, outG;
     bool timing = false;
     bool exactSpread = false;        // mrc_set_option(MRC_OPT_EXACT_SPREAD)
+    bool smrAllBands = false;        // mrc_set_option(MRC_OPT_SMR_ALL_BANDS)
     hipEvent_t ev[kKernelEvents] = {};
     double stageMs[3] = {0, 0, 0};
     double kernelMs[5] = {0, 0, 0, 0, 0};
@@ -222,6 +223,7 @@ int mrc_set_timing(mrc_handle* h, int enabled) {
 int mrc_set_option(mrc_handle* h, int option, int value) {
     if (!h) return MRC_ERR_INVALID;
     if (option == MRC_OPT_EXACT_SPREAD) { h->exactSpread = value != 0; return MRC_OK; }
+    if (option == MRC_OPT_SMR_ALL_BANDS) { h->smrAllBands = value != 0; return MRC_OK; }
     return fail(h, MRC_ERR_INVALID, "mrc_set_option: unknown option");
 }
 
@@ -348,7 +350,7 @@ int encode_core(mrc_handle* h, const DevShape& S, int64_t n, const void* chL, co
                                     4 * (int64_t)S.halfN, msSwitch, st));
     if (timing) MRC_HIP(h, hipEventRecord(h->ev[2], st));
     MRC_HIP(h, launch_smr(S, n, chL, chR, fmt, stride, offsets, lines, oscale, smr, nullptr, ws.peak.as<double>(),
-                          joint ? msSwitch : nullptr, h->exactSpread, st));
+                          (joint && !h->smrAllBands) ? msSwitch : nullptr, h->exactSpread, st));
     if (timing) MRC_HIP(h, hipEventRecord(h->ev[3], st));
     MRC_HIP(h, launch_alloc_quant(S, n, joint, lines, oscale, smr, resIn, msSwitch, bitAlloc, scaleFactor, mantissa,
                                   mantFmt, resOut, ws.peak.as<double>(), true, true, timing ? &h->ev[3] : nullptr, st));

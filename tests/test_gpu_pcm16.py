@@ -220,3 +220,26 @@ def test_two_shards_give_the_bytes_of_the_unsharded_stream(h):
     for world in (2, 3):
         parts = [chunks(*shard_frames(F, world, r))[0] for r in range(world)]
         assert b"".join(parts) == whole, world
+
+
+def test_joint_smr_skip_changes_no_output(h):
+    """smr_kernel leaves out the (signal, band) pairs the M/S switch does not select (ms_stereo.py:70-81: they never
+    reach the bit allocation).  With MRC_OPT_SMR_ALL_BANDS every SMR is computed: every output must be the same, on
+    content with mixed decisions, all-M/S and all-L/R bands, for every block shape."""
+    from mrcaudiocodec_amd import synth
+    MRC_OPT_SMR_ALL_BANDS = 2
+    s = synth.c3_stereo(40)
+    cases = [(s[0], s[1]), (s[0], 0.9 * s[0]), (s[0], synth.c2_noise(40, seed=99) * 3.0)]
+    for (a, b) in ((1024, 1024), (1024, 128), (128, 128), (128, 1024)):
+        for L, R in cases:
+            offs = np.arange(0, 30) * 1024 + 512
+            bl = np.stack([L[o:o + a + b] for o in offs]); br = np.stack([R[o:o + a + b] for o in offs])
+            got = h.encode_joint(bl, br, a, b)
+            h.set_option(MRC_OPT_SMR_ALL_BANDS, 1)
+            try:
+                full = h.encode_joint(bl, br, a, b)
+            finally:
+                h.set_option(MRC_OPT_SMR_ALL_BANDS, 0)
+            for k in INT_KEYS + ("ms_switch",):
+                assert np.array_equal(got[k], full[k]), (a, b, k)
+    assert 0 < got["ms_switch"].mean() <= 1
