@@ -143,15 +143,21 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void mdct_long_kernel(
     const double2 postLane = S.post[lane];
     __syncthreads();                            // W512 table visible to all waves
 
+    // REUSE (hop-overlapped stream): a wave walks kRun CONSECUTIVE FRAMES OF ONE SIGNAL.  Mono: consecutive units.
+    // Joint: wave w takes signal w (L, R, M, S) of the workgroup's kRun frames, unit = 4 frame + w, so its units are
+    // 4 apart -- and the four waves read the same L / R hops at the same time (one trip from HBM, three L2 hits).
+    static_assert(!REUSE || NSIG == 1 || NSIG == kWavesPerBlock, "joint reuse: one wave per signal");
     int64_t firstUnit, step;
-    if (REUSE) { firstUnit = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * kRun; step = 1; }
+    if (REUSE && NSIG == 1) { firstUnit = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * kRun; step = 1; }
+    else if (REUSE) { firstUnit = (int64_t)blockIdx.x * kRun * NSIG + wave; step = NSIG; }
     else { firstUnit = (int64_t)blockIdx.x * kWavesPerBlock * kRun + wave; step = kWavesPerBlock; }
 
     double rawE[8], rawO[8];                    // REUSE: raw second half of the previous block (= first half of this one)
     if (REUSE && firstUnit < nUnits) {
-        const int64_t off = firstUnit * stride;
+        const int64_t off = (firstUnit / NSIG) * stride;
+        const int sig0 = (int)(firstUnit % NSIG);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) load_pair<1, T>(chL, chR, off + 2 * (lane + 64 * c), 0, &rawE[c], &rawO[c]);
+        for (int c = 0; c < 8; ++c) load_pair<NSIG, T>(chL, chR, off + 2 * (lane + 64 * c), sig0, &rawE[c], &rawO[c]);
     }
 
     for (int it = 0; it < kRun; ++it) {
@@ -264,7 +270,10 @@ static void launch_long_t(const DevShape& S, int64_t nFrames, const T* chL, cons
     const int64_t perBlock = (int64_t)kWavesPerBlock * kRun;
     const unsigned grid = (unsigned)((nUnits + perBlock - 1) / perBlock);
     const dim3 block(kWave * kWavesPerBlock);
-    if (nsig == 4)
+    if (nsig == 4 && !offsets && stride == kM)       // hop-overlapped stereo stream: one wave per signal, hops kept
+        hipLaunchKernelGGL((mdct_long_kernel<4, true, T>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, offsets,
+                           lines, oscale);
+    else if (nsig == 4)
         hipLaunchKernelGGL((mdct_long_kernel<4, false, T>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, offsets,
                            lines, oscale);
     else if (!offsets && stride == kM)               // hop-overlapped stream: consecutive frames share a hop
