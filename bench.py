@@ -531,7 +531,7 @@ def host_pack_rate(np, ppac, out, n, threads=None):
     if threads:
         ppac.set_threads(threads)
     host = {k: out[k][:n].cpu().numpy() for k in ("overall_scale", "ms_switch", "scale_factor", "bit_alloc")}
-    mant = out["mantissa"][:n].cpu().numpy().view(np.uint16).astype(np.int32)
+    mant = out["mantissa"][:n].cpu().numpy().view(np.uint16)        # the 16-bit plane goes to the packer as it is
     args = (cfg, 1024, 1024, host["overall_scale"], host["ms_switch"], host["scale_factor"], host["bit_alloc"], mant)
     res = {"threads": ppac.get_threads(), "blocks": int(n)}
     samples = 2.0 * n * HOP

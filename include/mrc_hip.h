@@ -266,6 +266,14 @@ int mrc_pack_joint_blocks_with_tables(const mrc_config* cfg, int64_t n_blocks, i
                                       const int32_t* scale_factor, const int32_t* bit_alloc, const int32_t* mantissa,
                                       uint8_t* out, int64_t out_cap, int64_t* block_offset);
 
+/* The general form of the four packers above: joint = 0 / 1, huff_table_in NULL (price on the host when use_huffman)
+ * or given, and the mantissa plane in either format the encoder writes (MRC_MANTISSA_I32: int32_t*, MRC_MANTISSA_I16:
+ * uint16_t*, what mrc_encode_stream_pcm16 and mrc_dev_encode_ex deliver) -- no widening copy in between. */
+int mrc_pack_blocks_ex(const mrc_config* cfg, int64_t n_blocks, int n_channels, int a, int b, int joint, int use_huffman,
+                       const int32_t* huff_table_in, const int32_t* overall_scale, const int32_t* ms_switch,
+                       const int32_t* scale_factor, const int32_t* bit_alloc, const void* mantissa, int mantissa_format,
+                       uint8_t* out, int64_t out_cap, int64_t* block_offset, int32_t* huff_table, int32_t* bits_saved);
+
 /* Huffman table PRICING on the device (codecThem.py:136-180,202): per (frame, stream) the id of the cheapest
  * table (15 = raw) and bits_saved.  Lets a chained multi-stream encode carry the reservoir from block to block
  * without leaving the GPU; the bytes are produced later by mrc_pack_*.  bit_alloc [n][n_streams][nBands],

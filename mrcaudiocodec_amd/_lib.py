@@ -113,6 +113,8 @@ def _load():
         "mrc_pac_header": (C.c_int, [C.POINTER(MrcConfig), C.c_int, C.c_uint32, _u8p, C.c_int64, _i64p]),
         "mrc_pack_set_threads": (C.c_int, [C.c_int]),
         "mrc_pack_get_threads": (C.c_int, []),
+        "mrc_pack_blocks_ex": (C.c_int, [C.POINTER(MrcConfig), C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _i32p,
+                                         _i32p, _i32p, _i32p, _i32p, C.c_void_p, C.c_int, _u8p, C.c_int64, _i64p, _i32p, _i32p]),
         "mrc_pack_blocks_with_tables": (C.c_int, [C.POINTER(MrcConfig), C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p,
                                                   _i32p, _i32p, _i32p, _u8p, C.c_int64, _i64p]),
         "mrc_pack_joint_blocks_with_tables": (C.c_int, [C.POINTER(MrcConfig), C.c_int64, C.c_int, C.c_int, _i32p, _i32p,

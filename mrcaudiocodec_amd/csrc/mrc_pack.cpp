@@ -113,7 +113,8 @@ struct ChannelPlan {
 // codecThem.py:136-203.  The price of a table counts the escape VALUE itself as its code only
 // (lines 169-172) although the writer emits code + raw mantissa for it (194-200): kept, so the choice and
 // bits_saved equal the reference's; mantBits is what is really written (pacfileThem.py:685-703).
-int64_t written_bits(const int32_t* ba, const int32_t* mant, const std::vector<int>& nLines, int t) {
+template <class MantT>
+int64_t written_bits(const int32_t* ba, const MantT* mant, const std::vector<int>& nLines, int t) {
     // what the writer emits for table t (pacfileThem.py:685-703): code, plus the raw mantissa after an escape code
     const int nb = (int)nLines.size();
     int64_t written = 0;
@@ -123,7 +124,7 @@ int64_t written_bits(const int32_t* ba, const int32_t* mant, const std::vector<i
         if (ba[b]) {
             int64_t codeBits = 0, rawFollows = 0;
             for (int i = 0; i < n; ++i) {
-                const uint32_t e = kLut.emit[t][lut_index(mant[k + i])];
+                const uint32_t e = kLut.emit[t][lut_index((int32_t)mant[k + i])];
                 codeBits += (e >> 16) & 0x7fffu;
                 rawFollows += e >> 31;
             }
@@ -134,7 +135,8 @@ int64_t written_bits(const int32_t* ba, const int32_t* mant, const std::vector<i
     return written;
 }
 
-ChannelPlan plan_channel(const int32_t* ba, const int32_t* mant, const std::vector<int>& nLines, int useHuffman,
+template <class MantT>
+ChannelPlan plan_channel(const int32_t* ba, const MantT* mant, const std::vector<int>& nLines, int useHuffman,
                          int givenTable = -1) {
     const int nb = (int)nLines.size();
     int64_t raw = 0;
@@ -153,7 +155,7 @@ ChannelPlan plan_channel(const int32_t* ba, const int32_t* mant, const std::vect
         if (ba[b]) {
             uint64_t lens = 0, misses = 0;           // four 16-bit sums each
             for (int i = 0; i < n; ++i) {
-                const unsigned idx = lut_index(mant[k + i]);
+                const unsigned idx = lut_index((int32_t)mant[k + i]);
                 lens += kLut.lenSum[idx];
                 misses += kLut.miss[idx];
             }
@@ -171,7 +173,8 @@ ChannelPlan plan_channel(const int32_t* ba, const int32_t* mant, const std::vect
     return plan;
 }
 
-void write_band_records(BitWriter& w, const mrc_config& cfg, const int32_t* sf, const int32_t* ba, const int32_t* mant,
+template <class MantT>
+void write_band_records(BitWriter& w, const mrc_config& cfg, const int32_t* sf, const int32_t* ba, const MantT* mant,
                         const std::vector<int>& nLines, int table) {
     const int nb = (int)nLines.size();
     int k = 0;
@@ -182,14 +185,14 @@ void write_band_records(BitWriter& w, const mrc_config& cfg, const int32_t* sf, 
               cfg.n_mant_size_bits + cfg.n_scale_bits);
         const int n = nLines[b];
         if (bits) {
-            const int32_t* m = mant + k;
+            const MantT* m = mant + k;
             if (table == kRawTable) {
                 for (int i = 0; i < n; ++i) w.put((uint32_t)m[i], bits);
             } else {
                 const uint32_t* emit = kLut.emit[table];
                 const uint32_t rawMask = (1u << bits) - 1u;            // bits <= 16
                 for (int i = 0; i < n; ++i) {
-                    const uint32_t e = emit[lut_index(m[i])];
+                    const uint32_t e = emit[lut_index((int32_t)m[i])];
                     const int len = (int)((e >> 16) & 0x7fffu);
                     if (e >> 31) w.put(((e & 0xffffu) << bits) | ((uint32_t)m[i] & rawMask), len + bits);   // code + raw: <= 9 + 16 bits
                     else w.put(e & 0xffffu, len);
@@ -361,10 +364,13 @@ int mrc_pac_header(const mrc_config* cfg, int n_channels, uint32_t num_samples, 
     return MRC_OK;
 }
 
+}  // extern "C"
+
 // One chunk pair/set per block, exactly the bytes WriteDataBlock / JointWriteDataBlock append.
+template <class MantT>
 static int pack_blocks(const mrc_config* cfg, int64_t n, int nch, int a, int b, int joint, int use_huffman,
                        const int32_t* overall_scale, const int32_t* ms_switch, const int32_t* scale_factor,
-                       const int32_t* bit_alloc, const int32_t* mantissa, uint8_t* out, int64_t out_cap,
+                       const int32_t* bit_alloc, const MantT* mantissa, uint8_t* out, int64_t out_cap,
                        int64_t* block_offset, int32_t* huff_table, int32_t* bits_saved,
                        const int32_t* huff_table_in = nullptr) {
     if (!shape_ok(cfg, a, b) || n < 0 || !overall_scale || !scale_factor || !bit_alloc || !mantissa || !out ||
@@ -436,6 +442,8 @@ static int pack_blocks(const mrc_config* cfg, int64_t n, int nch, int a, int b, 
     return MRC_OK;
 }
 
+extern "C" {
+
 int mrc_pack_set_threads(int n_threads) {
     if (n_threads < 1 || n_threads > 1024) return MRC_ERR_INVALID;
     g_packThreads.store(n_threads);
@@ -477,6 +485,22 @@ int mrc_pack_joint_blocks_with_tables(const mrc_config* cfg, int64_t n_blocks, i
 }
 
 int mrc_pack_get_threads(void) { return g_packThreads.load(); }
+
+int mrc_pack_blocks_ex(const mrc_config* cfg, int64_t n_blocks, int n_channels, int a, int b, int joint, int use_huffman,
+                       const int32_t* huff_table_in, const int32_t* overall_scale, const int32_t* ms_switch,
+                       const int32_t* scale_factor, const int32_t* bit_alloc, const void* mantissa, int mantissa_format,
+                       uint8_t* out, int64_t out_cap, int64_t* block_offset, int32_t* huff_table, int32_t* bits_saved) {
+    if (joint && n_channels != 2) return MRC_ERR_INVALID;
+    if (mantissa_format == MRC_MANTISSA_I16)
+        return pack_blocks(cfg, n_blocks, n_channels, a, b, joint ? 1 : 0, use_huffman, overall_scale, ms_switch,
+                           scale_factor, bit_alloc, (const uint16_t*)mantissa, out, out_cap, block_offset, huff_table,
+                           bits_saved, huff_table_in);
+    if (mantissa_format == MRC_MANTISSA_I32)
+        return pack_blocks(cfg, n_blocks, n_channels, a, b, joint ? 1 : 0, use_huffman, overall_scale, ms_switch,
+                           scale_factor, bit_alloc, (const int32_t*)mantissa, out, out_cap, block_offset, huff_table,
+                           bits_saved, huff_table_in);
+    return MRC_ERR_INVALID;
+}
 
 
 // ---- decode side ---------------------------------------------------------------------------------------------

@@ -68,55 +68,47 @@ def header(cfg, n_channels, num_samples):
     return out[:n.value].tobytes()
 
 
-def _run_pack(fn, cfg, n, nch, a, b, joint, args, given_tables=None):
+def _pack(cfg, a, b, joint, overall_scale, ms_switch, scale_factor, bit_alloc, mantissa, use_huffman, huff_table):
+    """mrc_pack_blocks_ex: the mantissa plane goes in as it is -- int32, or the uint16 codes the PCM16 / mantissa16
+    encode paths deliver (an int16 view of them is taken as uint16)."""
+    sf, ba, osc = _i32(scale_factor), _i32(bit_alloc), _i32(overall_scale)
+    n, nch = sf.shape[0], sf.shape[1]
+    m = np.asarray(mantissa)
+    if m.dtype == np.int16:
+        m = m.view(np.uint16)
+    if m.dtype == np.uint16:
+        m, fmt = np.ascontiguousarray(m), 1
+    else:
+        m, fmt = _i32(m), 0
+    sw = None if ms_switch is None else _i32(ms_switch)
+    ht = None if huff_table is None else _i32(huff_table).reshape(n, nch)
     bound = lib.mrc_pack_bound(C.byref(cfg), int(a), int(b), nch, int(joint))
     if bound < 0:
         raise MrcError("mrc_pack_bound failed (%d)" % bound)
     out = np.empty(max(1, n * bound), dtype=np.uint8)          # every byte up to offs[n] is written by the packer
     offs = np.zeros(n + 1, dtype=np.int64)
-    if given_tables is not None:
-        _check(fn(*args, out.ctypes.data_as(_u8p), out.size, offs.ctypes.data_as(_i64p)), fn.__name__)
-        return out[:offs[n]], offs, given_tables, None
-    table = np.zeros((n, nch), dtype=np.int32)
-    saved = np.zeros((n, nch), dtype=np.int32)
-    _check(fn(*args, out.ctypes.data_as(_u8p), out.size, offs.ctypes.data_as(_i64p), table.ctypes.data_as(_i32p),
-              saved.ctypes.data_as(_i32p)), fn.__name__)
-    return out[:offs[n]], offs, table, saved
+    table = np.zeros((n, nch), dtype=np.int32) if ht is None else None
+    saved = np.zeros((n, nch), dtype=np.int32) if ht is None else None
+    p32 = lambda arr: None if arr is None else arr.ctypes.data_as(_i32p)
+    _check(lib.mrc_pack_blocks_ex(C.byref(cfg), n, nch, int(a), int(b), int(joint), int(bool(use_huffman)), p32(ht), p32(osc),
+                                  p32(sw), p32(sf), p32(ba), m.ctypes.data_as(C.c_void_p), fmt, out.ctypes.data_as(_u8p),
+                                  out.size, offs.ctypes.data_as(_i64p), p32(table), p32(saved)), "mrc_pack_blocks_ex")
+    return out[:offs[n]], offs, (ht if ht is not None else table), saved
 
 
 def pack_blocks(cfg, a, b, overall_scale, scale_factor, bit_alloc, mantissa, use_huffman=True, huff_table=None):
     """WriteDataBlock for n blocks of nch independent channels.  overall_scale [n][nch], scale_factor /
-    bit_alloc [n][nch][nBands], mantissa [n][nch][N/2] dense.  -> (bytes array, block offsets [n+1],
+    bit_alloc [n][nch][nBands], mantissa [n][nch][N/2] dense (int32 or uint16).  -> (bytes array, block offsets [n+1],
     huffTable [n][nch], bits_saved [n][nch]).  huff_table [n][nch] given (e.g. by Handle.dev_huffman_gain): the
     host skips the pricing of the four tables and bits_saved is None."""
-    sf, ba, m = _i32(scale_factor), _i32(bit_alloc), _i32(mantissa)
-    osc = _i32(overall_scale)
-    n, nch = sf.shape[0], sf.shape[1]
-    if huff_table is not None:
-        ht = _i32(huff_table).reshape(n, nch)
-        args = (C.byref(cfg), n, nch, int(a), int(b), ht.ctypes.data_as(_i32p), osc.ctypes.data_as(_i32p),
-                sf.ctypes.data_as(_i32p), ba.ctypes.data_as(_i32p), m.ctypes.data_as(_i32p))
-        return _run_pack(lib.mrc_pack_blocks_with_tables, cfg, n, nch, a, b, 0, args, given_tables=ht)
-    args = (C.byref(cfg), n, nch, int(a), int(b), int(bool(use_huffman)), osc.ctypes.data_as(_i32p),
-            sf.ctypes.data_as(_i32p), ba.ctypes.data_as(_i32p), m.ctypes.data_as(_i32p))
-    return _run_pack(lib.mrc_pack_blocks, cfg, n, nch, a, b, 0, args)
+    return _pack(cfg, a, b, 0, overall_scale, None, scale_factor, bit_alloc, mantissa, use_huffman, huff_table)
 
 
 def pack_joint_blocks(cfg, a, b, overall_scale, ms_switch, scale_factor, bit_alloc, mantissa, use_huffman=True,
                       huff_table=None):
     """JointWriteDataBlock for n blocks.  overall_scale [n][4], ms_switch [n][nBands], others [n][2][...];
     huff_table [n][2] as in pack_blocks."""
-    sf, ba, m = _i32(scale_factor), _i32(bit_alloc), _i32(mantissa)
-    osc, sw = _i32(overall_scale), _i32(ms_switch)
-    n = sf.shape[0]
-    if huff_table is not None:
-        ht = _i32(huff_table).reshape(n, 2)
-        args = (C.byref(cfg), n, int(a), int(b), ht.ctypes.data_as(_i32p), osc.ctypes.data_as(_i32p),
-                sw.ctypes.data_as(_i32p), sf.ctypes.data_as(_i32p), ba.ctypes.data_as(_i32p), m.ctypes.data_as(_i32p))
-        return _run_pack(lib.mrc_pack_joint_blocks_with_tables, cfg, n, 2, a, b, 1, args, given_tables=ht)
-    args = (C.byref(cfg), n, int(a), int(b), int(bool(use_huffman)), osc.ctypes.data_as(_i32p), sw.ctypes.data_as(_i32p),
-            sf.ctypes.data_as(_i32p), ba.ctypes.data_as(_i32p), m.ctypes.data_as(_i32p))
-    return _run_pack(lib.mrc_pack_joint_blocks, cfg, n, 2, a, b, 1, args)
+    return _pack(cfg, a, b, 1, overall_scale, ms_switch, scale_factor, bit_alloc, mantissa, use_huffman, huff_table)
 
 
 def encode_stereo_stream(handle, stream, shapes, use_huffman=True, num_samples=None):

@@ -150,3 +150,23 @@ def test_pack_with_given_tables_equals_priced():
     from mrcaudiocodec_amd._lib import MrcError
     with pytest.raises(MrcError):
         ppac.pack_joint_blocks(*args, huff_table=np.full_like(table, 7))
+
+
+def test_pack_accepts_the_16_bit_mantissa_plane():
+    """The PCM16 / mantissa16 encode paths deliver uint16 codes: the packer takes them as they are (also through an
+    int16 view, which is how torch holds them) and writes the same bytes as from the int32 plane."""
+    s = synth.c3_stereo(10)
+    bl, br = np.array(fast.blocks_from_stream(s[0], 1024)), np.array(fast.blocks_from_stream(s[1], 1024))
+    r = fast.encode_joint_batch(bl, br, 1024, 1024)
+    assert r["mantissa"].max() > 32767                          # sign bit of a 16-bit code set: not an int16 value
+    cfg = ppac.make_config()
+    args = (cfg, 1024, 1024, r["overall_scale"], r["ms_switch"], r["scale_factor"], r["bit_alloc"])
+    want = ppac.pack_joint_blocks(*args, r["mantissa"].astype(np.int32), use_huffman=True)
+    m16 = r["mantissa"].astype(np.uint16)
+    for plane in (m16, m16.view(np.int16)):
+        got = ppac.pack_joint_blocks(*args, plane, use_huffman=True)
+        assert got[0].tobytes() == want[0].tobytes() and np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+    mono = fast.encode_mono_batch(bl, 1024, 1024)
+    margs = (cfg, 1024, 1024, mono["overall_scale"][:, None], mono["scale_factor"][:, None, :], mono["bit_alloc"][:, None, :])
+    assert ppac.pack_blocks(*margs, mono["mantissa"][:, None, :].astype(np.uint16))[0].tobytes() == \
+        ppac.pack_blocks(*margs, mono["mantissa"][:, None, :].astype(np.int32))[0].tobytes()

@@ -33,8 +33,9 @@ def main():
     bl, br = np.array(fast.blocks_from_stream(s[0], 1024)), np.array(fast.blocks_from_stream(s[1], 1024))
     r = fast.encode_joint_batch(bl, br, 1024, 1024)
     reps = -(-a.blocks // a.seed_frames)
-    tile = lambda x: np.ascontiguousarray(np.concatenate([x] * reps)[:a.blocks])
+    tile = lambda x: np.ascontiguousarray(np.concatenate([x] * reps)[:a.blocks], dtype=np.int32)   # what the device delivers
     osc, sw, sf, ba, m = (tile(r[k]) for k in ("overall_scale", "ms_switch", "scale_factor", "bit_alloc", "mantissa"))
+    m16 = m.astype(np.uint16)                                    # ... or the 16-bit plane of the PCM16 / mantissa16 paths
     cfg = ppac.make_config()
     samples = a.blocks * 1024 * 2
     out = {"blocks": a.blocks, "samples": samples}
@@ -53,6 +54,7 @@ def main():
         res["raw"] = timed(lambda: ppac.pack_joint_blocks(cfg, 1024, 1024, osc, sw, sf, ba, m, use_huffman=False))
         res["huffman_priced_on_host"] = timed(lambda: ppac.pack_joint_blocks(cfg, 1024, 1024, osc, sw, sf, ba, m, use_huffman=True))
         res["huffman_tables_given"] = timed(lambda: ppac.pack_joint_blocks(cfg, 1024, 1024, osc, sw, sf, ba, m, huff_table=tables))
+        res["huffman_priced_on_host_uint16_plane"] = timed(lambda: ppac.pack_joint_blocks(cfg, 1024, 1024, osc, sw, sf, ba, m16, use_huffman=True))
         data, offs, _, _ = ppac.pack_joint_blocks(cfg, 1024, 1024, osc, sw, sf, ba, m, use_huffman=True)
         buf = ppac.header(cfg, 2, a.blocks * 1024) + data.tobytes()
         cfg2, nch, ns, off = ppac.read_header(buf)
