@@ -158,7 +158,11 @@ def test_pack_accepts_the_16_bit_mantissa_plane():
     s = synth.c3_stereo(10)
     bl, br = np.array(fast.blocks_from_stream(s[0], 1024)), np.array(fast.blocks_from_stream(s[1], 1024))
     r = fast.encode_joint_batch(bl, br, 1024, 1024)
-    assert r["mantissa"].max() > 32767                          # sign bit of a 16-bit code set: not an int16 value
+    # make some codes use all 16 bits (sign bit of a 16-bit allocation set: not representable as int16)
+    r["bit_alloc"][0, 0, 3] = 16
+    lo = int(np.sum(fast.bands_for(1024, 1024).nLines[:3]))
+    r["mantissa"][0, 0, lo:lo + 4] = [0x8000, 0xFFFF, 0x8001, 0x7FFF]
+    assert r["mantissa"].max() > 32767
     cfg = ppac.make_config()
     args = (cfg, 1024, 1024, r["overall_scale"], r["ms_switch"], r["scale_factor"], r["bit_alloc"])
     want = ppac.pack_joint_blocks(*args, r["mantissa"].astype(np.int32), use_huffman=True)
