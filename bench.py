@@ -480,7 +480,7 @@ def main():
             label = dict(KERNEL_LABEL)
             if (a, b) != (HOP, HOP):
                 label["mdct"] = "mdct_kernel"
-            rr = kernel_report(list(zip(KERNEL_NAMES, km)), abk, o.numel(), tb, label)
+            rr = kernel_report(list(zip(KERNEL_NAMES, km)), abk, o.numel(), {}, label)   # (PMC traffic: per config, below)
             for r in rr:
                 r["shape"] = "%dx%d" % (a, b)
             rows_b += rr
@@ -490,7 +490,10 @@ def main():
                         "blocks, one launch set per shape",
             "value": round(float(hops) * HOP * args.steps / eb / 1e6, 3), "unit": "Msamples/s", "hops": hops,
             "ms_per_step": round(eb / args.steps * 1e3, 4), "per_shape": per_shape,
-            "roofline": roofline_of(rows_b, {"traffic_source": tb_src}), "kernels": rows_b}
+            "roofline": roofline_of(rows_b, {"traffic_source": tb_src,
+                                             "traffic": None if "smr_kernel" not in tb else round(tb["smr_kernel"] * hops),
+                                             "traffic_note": "smr_kernel, all four block shapes of a step together"}),
+            "hbm_traffic_bytes_per_hop": {k: v for k, v in tb.items()} or None, "kernels": rows_b}
         line["configs"] = cfgs
         del xs, groups
 

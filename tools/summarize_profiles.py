@@ -6,11 +6,15 @@ Turn rocprofv3 output directories (gpurun_out/, scratch) into the small summarie
                            MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x2: wide coalesced reads are
                            tallied at half their bytes; calibrated here with tools/calibrate_fetch.py:
                            a known 1,073,741,824-byte read reports 571,000 KB), per launch and per frame.
-Usage: summarize_profiles.py <tag> <frames_per_launch> <stats_dir> <fetch_dir> <write_dir>
+Usage: summarize_profiles.py <tag> <frames_per_step> <stats_dir> <fetch_dir> <write_dir> [steps]
+`steps` = encode steps the profiled command ran (warm-up included).  Given, the counters of ALL dispatches of a kernel
+are summed and divided by it (a block-switched step launches each kernel once per block shape); omitted, the mean per
+dispatch is taken (one launch per step).
 """
 import collections, csv, glob, json, os, re, sys
 
 tag, frames, stats_dir, fetch_dir, write_dir = sys.argv[1], int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
+steps = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
 
 def kname(s):
@@ -30,10 +34,10 @@ def counters(d):
         k = kname(r["Kernel_Name"])
         if k:
             agg[k].append(float(r["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in agg.items()}
+    return {k: (sum(v) / steps if steps else sum(v) / len(v)) for k, v in agg.items()}
 
 fetch, write = counters(fetch_dir), counters(write_dir)
-out = {"frames_per_launch": frames, "unit_note": "FETCH_SIZE/WRITE_SIZE are KB; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
+out = {"frames_per_launch": frames, "steps_profiled": steps or None, "unit_note": "FETCH_SIZE/WRITE_SIZE are KB; hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024",
        "kernels": {}}
 for k in fetch:
     b = (2 * fetch[k] + write.get(k, 0.0)) * 1024
