@@ -53,11 +53,15 @@ def read_wav(path, hop=1024):
     return rate, n_ch, num_samples, x
 
 
-def encode_wav(in_path, out_path=None, use_huffman=True, device_id=0, handle=None):
+def encode_wav(in_path, out_path=None, use_huffman=True, device_id=0, handle=None, exact_spread=False):
+    """exact_spread: evaluate the masker spreading operation by operation like psychoac.py:68-78 (MRC_OPT_EXACT_SPREAD,
+    ~30x slower kernel; irrelevant for the time of one file).  Both modes give the reference driver's bytes on every
+    fixture and sweep; neither is bit-identical by construction (README.md, "Parity")."""
     rate, n_ch, num_samples, hops = read_wav(in_path)
     if n_ch != 2:
         raise ValueError("stereo input only (the reference's JointEncode indexes data[0], data[1])")
     h = handle if handle is not None else Handle(sample_rate=rate, device_id=device_id)
+    h.set_option(1, 1 if exact_spread else 0)
     try:
         stream = np.concatenate([np.zeros((2, h.cfg.n_mdct_lines)), hops], axis=1)
         shapes = transient.block_shapes(h, stream)
@@ -65,6 +69,7 @@ def encode_wav(in_path, out_path=None, use_huffman=True, device_id=0, handle=Non
             raise ValueError("file too short: fewer than two hops")
         data = pacfile.encode_stereo_stream(h, stream, shapes, use_huffman, num_samples=num_samples)
     finally:
+        h.set_option(1, 0)
         if handle is None:
             h.close()
     if out_path:
@@ -105,13 +110,15 @@ def main(argv=None):
     ap.add_argument("dst")
     ap.add_argument("-d", "--decode", action="store_true")
     ap.add_argument("--no-huffman", action="store_true")
+    ap.add_argument("--exact-spread", action="store_true",
+                    help="masker spreading operation by operation as in psychoac.py:68-78 (slower kernel)")
     ap.add_argument("--device", type=int, default=0)
     a = ap.parse_args(argv)
     if a.decode:
         pcm = decode_pac_file(a.src, a.dst, a.device)
         print("%s: %d channels x %d samples" % (a.dst, pcm.shape[0], pcm.shape[1]))
         return
-    data = encode_wav(a.src, a.dst, not a.no_huffman, a.device)
+    data = encode_wav(a.src, a.dst, not a.no_huffman, a.device, exact_spread=a.exact_spread)
     print("%s: %d bytes" % (a.dst, len(data)))
 
 

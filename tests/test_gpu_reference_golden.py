@@ -117,6 +117,7 @@ def test_cli_pac_bytes_equal_reference_cli(tmp_path, case):
         f.write(cli.wav_bytes(g[case + "_pcm"], int(g[case + "_rate"])))
     assert cli.encode_wav(path, use_huffman=True) == g[case + "_pac"].tobytes()
     assert cli.encode_wav(path, use_huffman=False) == g[case + "_pac_raw"].tobytes()
+    assert cli.encode_wav(path, use_huffman=True, exact_spread=True) == g[case + "_pac"].tobytes()
 
 
 @pytest.mark.parametrize("case", ["a48", "b44"])
