@@ -951,6 +951,9 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
         if (H / 2 <= S.peakLast + 1) lay.twOff = 4 * H;
         else { total += total & 1; lay.twOff = total; total += H / 2; }
     }
+#ifdef MRC_PROFILE_EXTRA_LDS                     // profiling aid: pad the workgroup's LDS (occupancy experiments)
+    total += MRC_PROFILE_EXTRA_LDS / 8;
+#endif
     const size_t lds = (size_t)total * sizeof(double);
     // blocks of up to 128 lines (two 64-line chunks) run as two-wave workgroups: no idle waves holding CU wave slots
     const dim3 grid((unsigned)(nFrames * nsig));
