@@ -51,6 +51,8 @@ constexpr int kFarMaxOrder = 20;
 constexpr int kFarMinMaskers = MRC_FAR_MIN;
 #ifdef MRC_FAR_STRICT       // round-1 limits: truncated tail < 1e-17 of each term
 constexpr double kFarLimit8 = 0.052, kFarLimit12 = 0.27, kFarLimit16 = 0.68, kFarLimit20 = 1.0;
+#elif defined(MRC_FAR_TOL13)  // experiment: truncated tail < 1e-13 of each term
+constexpr double kFarLimit8 = 0.1466, kFarLimit12 = 0.5436, kFarLimit16 = 1.1529, kFarLimit20 = 1.9056;
 #else                       // truncated tail < 1e-15 of each term (2 % faster: more chunks get by with a lower order; the
 constexpr double kFarLimit8 = 0.089, kFarLimit12 = 0.397, kFarLimit16 = 0.94, kFarLimit20 = 1.3;   // thresholds move < 1e-14 dB)
 #endif
@@ -266,6 +268,63 @@ __device__ __forceinline__ double far_group(const double* __restrict__ mt, int n
     for (int j = J - 1; j >= 0; --j) p = fma(p, d, B[j]);
     return p * exp2_tab64(slMid, d, e2tab);
 }
+
+
+// MRC_FAR_MFMA = 1: far-field sums through v_mfma_f64_16x16x4 (below).  Correct (all GPU tests pass) and 2 200 VALU
+// instructions per frame shorter, but 19 % SLOWER (smr_kernel 5.94 vs 4.97 ms per 131 072 frames, round 2): on MI355X an
+// fp64 MFMA holds the SIMD's fp64 pipe for its 64 cycles -- tools/valu_rates.hip: a dependent chain issues one per 64
+// cycles, and 1 MFMA + 8 independent v_fma_f64 take 106 cycles, the sum of the two, with 1, 2 or 4 waves per SIMD -- so the
+// ~370 matrix instructions per frame cost what 5 900 fp64 VALU instructions would.  The matrix pipe is no second fp64 engine
+// on this chip (78.6 TFLOP/s either way); kept as a build option for the record.
+#ifndef MRC_FAR_MFMA
+#define MRC_FAR_MFMA 0
+#endif
+#if MRC_FAR_MFMA
+// ---- far field on the matrix pipe.
+// A RUN of adjacent chunks (all taken by one wave) shares ONE expansion centre C: with e_m = I_m 2^(s_m (C - 1/2 - z_m)),
+// a_m = s_m ln2 and A the middle slope, the far maskers of a line at distance d = z - C from the centre sum to
+//   exp(A d) sum_j d^j S_j,   S_j = 1/j! sum_{m < nFar} e_m (a_m - A)^j,
+// and the runs's chunks differ only in nFar (non-decreasing with the chunk): the S_j of chunk c+1 are those of chunk c plus
+// the maskers in between.  So the maskers are walked ONCE per run, 64 at a time (a lane per masker: one 2^x and the
+// powers of a_m - A), in SEGMENTS that end where a chunk's nFar is reached, and the per-lane terms are summed over the
+// wave by v_mfma_f64_16x16x4: with the lane's term as the A operand (A[i][k] = lane 16 k + i) and a 0/1 selector as the
+// B operand (B[k][c] = [c == j]) the accumulator column j collects sum_k term_j(16 k + i) for the 16 rows i -- no VALU
+// additions, no cross-lane shuffles, and the accumulator simply keeps running from one chunk of the run to the next.
+// When a chunk's nFar is reached, the four accumulator registers of a lane are added, scaled by 1/j! and summed over the
+// rows by one more MFMA against a matrix of ones: every lane then holds S_(lane & 15), and the polynomial is evaluated
+// with v_fmac_f64 ... row_newbcast:j (the coefficient comes straight from lane j of the 16-lane row).
+// The VALU keeps: one 2^x per masker and RUN (not per chunk), and 3 instructions per order and segment.
+typedef double double4v __attribute__((__vector_size__(4 * sizeof(double))));
+// largest |x| = (half slope range) x (half Bark span of the run) for NB = 8 / 12 / 16 coefficients: truncated tail
+// x^NB / NB! e^x below 1e-15 of each term
+constexpr double kRunLimit8 = 0.0499, kRunLimit12 = 0.2903, kRunLimit16 = 0.7494;
+
+template <int J>
+__device__ __forceinline__ double fmac_row_bcast(double acc, double coef, double x) {
+    // acc += (coef of lane J of this lane's 16-lane row) * x
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(coef), "v"(x), "n"(J));
+    return acc;
+}
+template <int NB, int J = 1>
+__device__ __forceinline__ double row_poly(double p, double coef, double dpow, double d) {
+    if constexpr (J < NB) {
+        dpow *= d;
+        p = fmac_row_bcast<J>(p, coef, dpow);
+        return row_poly<NB, J + 1>(p, coef, dpow, d);
+    } else {
+        return p;
+    }
+}
+template <int NB, int J = 0>
+__device__ __forceinline__ void mfma_terms(double4v& D, double t, double da, int lane15) {
+    if constexpr (J < NB) {
+        const double sel = (lane15 == J) ? 1.0 : 0.0;
+        D = __builtin_amdgcn_mfma_f64_16x16x4f64(t, sel, D, 0, 0, 0);
+        if constexpr (J + 1 < NB) t *= da;
+        mfma_terms<NB, J + 1>(D, t, da, lane15);
+    }
+}
+#endif
 
 // kLog10Tab as [j][4] for the LDS copy
 struct LogTabDev { double v[kLogTabEntries * 4]; };
@@ -724,7 +783,21 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
         // global-load latency is never exposed between the loops of a chunk)
         struct LineConst { double z, quiet, lowE, x; int bnd; };
         const int waveU = __builtin_amdgcn_readfirstlane(wave);          // (uniform: chunk indices stay in SGPRs)
+#if MRC_FAR_MFMA
+        // chunks are dealt to the waves in adjacent PAIRS (pair s of a wave: cheap low pairs alternate with expensive high
+        // ones), so that a far-field run can span two -- for the wave that gets the middle of the spectrum, four -- chunks;
+        // blocks with fewer than two chunks per wave keep single chunks
+        const bool pairMode = nChunks >= 2 * nWaves;
+        auto chunk_of = [&](int i) {
+            if (pairMode) {
+                const int sIdx = i >> 1;
+                return 2 * (sIdx * nWaves + ((sIdx & 1) ? (nWaves - 1 - waveU) : waveU)) + (i & 1);
+            }
+            return i * nWaves + ((i & 1) ? (nWaves - 1 - waveU) : waveU);
+        };
+#else
         auto chunk_of = [&](int i) { return i * nWaves + ((i & 1) ? (nWaves - 1 - waveU) : waveU); };
+#endif
         auto load_consts = [&](int i) {
             const int kc = min(chunk_of(i) * kWave + lane, M - 1);
             return LineConst{S.zb[kc], S.quiet[kc], S.lowE[kc], X[kc], S.bandOfLine[kc]};
@@ -735,7 +808,14 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
         // Rounds of up to four chunks per wave.  Pass 1 evaluates the FAR FIELD of the round's chunks -- the only part
         // that needs a large register tile (the expansion coefficients) -- and keeps one value per line; pass 2 does
         // the near maskers, the in-band and lower-side sums and the SPL conversions with that value added in.
-        for (int i0 = 0; chunk_of(i0) < nChunks; i0 += 4) {
+#if defined(MRC_PROFILE_NOSWEEP)                  // profiling aids (wrong results): no unit / units with (unit & n) skip the sweep
+        const bool sweepOn = false;
+#elif defined(MRC_PROFILE_HALFSWEEP)
+        const bool sweepOn = !(unit & MRC_PROFILE_HALFSWEEP);
+#else
+        const bool sweepOn = true;
+#endif
+        for (int i0 = 0; sweepOn && chunk_of(i0) < nChunks; i0 += 4) {
         // ---- pass 1: far field.  Maskers [0, nFar) lie more than 1/2 Bark below EVERY line of the chunk; their sum is
         // evaluated by far_group() for the whole chunk (one group) or its two halves.  The expansion is in
         // (slope - middle slope of the frame) x (distance from the group's centre): the order follows from
@@ -745,6 +825,79 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
         __builtin_amdgcn_s_setprio(MRC_FAR_PRIO);
         double far0 = 0.0, far1 = 0.0, far2 = 0.0, far3 = 0.0;
         unsigned farMask = 0;                            // bit u: chunk u of the round took the far field
+#if MRC_FAR_MFMA
+        {
+            const int lane15 = lane & 15;
+            const double invFact = kInvFactorial[lane15];
+            // maskers more than 1/2 Bark below every line of chunk c -- 0: the chunk takes no far field
+            auto far_count = [&](int c) -> int {
+                const int kc = min(c * kWave + lane, M - 1);
+                if (!__any(needBand[S.bandOfLine[kc]])) return 0;                  // (see needBand)
+                const int nf = __builtin_amdgcn_readfirstlane((int)nUpArr[kc]);    // nUp of the chunk's first line
+                return (nf < kFarMinMaskers || (MRC_PROFILE_SKIP & 1)) ? 0 : nf;
+            };
+            for (int u = 0; u < 4;) {
+                const int c = chunk_of(i0 + u);
+                if (c >= nChunks) break;
+                const int nf = far_count(c);
+                const double zFirst = S.zb[c * kWave];
+                double zLast = S.zb[min(c * kWave + kWave - 1, M - 1)];
+                if (!nf || spreadHalf * (0.5 * (zLast - zFirst)) > kRunLimit16) { ++u; continue; }
+                // extend the run over the adjacent chunks of this wave while the expansion still converges
+                int uEnd = u, nEnd = nf;
+                while (uEnd + 1 < 4) {
+                    const int c2 = chunk_of(i0 + uEnd + 1);
+                    if (c2 != c + (uEnd + 1 - u) || c2 >= nChunks) break;
+                    const int nf2 = far_count(c2);
+                    const double zLast2 = S.zb[min(c2 * kWave + kWave - 1, M - 1)];
+                    if (!nf2 || spreadHalf * (0.5 * (zLast2 - zFirst)) > kRunLimit16) break;
+                    zLast = zLast2; nEnd = nf2; ++uEnd;
+                }
+                const double need = spreadHalf * (0.5 * (zLast - zFirst));
+                const double C = 0.5 * (zFirst + zLast), cq = C - 0.5;
+                const int nb = need <= kRunLimit8 ? 8 : need <= kRunLimit12 ? 12 : 16;
+                double4v D = {0.0, 0.0, 0.0, 0.0};
+                int cur = u, curEnd = nf;
+                for (int m0 = 0; m0 < nEnd && cur <= uEnd; m0 += kWave) {
+                    const int m = m0 + lane, mm = min(m, nEnd - 1);
+                    const double I = mt[4 * mm], zm = mt[4 * mm + 1], sl = mt[4 * mm + 2];
+                    const double e = (m < nEnd) ? I * exp2_tab64(sl, cq - zm, e2tab) : 0.0;
+                    const double da = (sl - slMid) * (0.6931471805599453094 / kExpTabD);   // slope offset in nats per Bark
+                    int segLo = m0;
+                    while (cur <= uEnd) {
+                        const int segHi = min(curEnd, m0 + kWave);
+                        if (segHi > segLo) {
+                            const double t = (m >= segLo && m < segHi) ? e : 0.0;
+                            if (nb == 8) mfma_terms<8>(D, t, da, lane15);
+                            else if (nb == 12) mfma_terms<12>(D, t, da, lane15);
+                            else mfma_terms<16>(D, t, da, lane15);
+                            segLo = segHi;
+                        }
+                        if (curEnd > m0 + kWave) break;          // the rest of this chunk's maskers: next 64
+                        // chunk `cur` has all its far maskers: coefficients, then the polynomial on its lines
+                        const int cc = chunk_of(i0 + cur);
+                        const double z = S.zb[min(cc * kWave + lane, M - 1)];
+                        const double d = z - C;
+                        const double4v Z = {0.0, 0.0, 0.0, 0.0};
+                        const double part = ((D[0] + D[1]) + (D[2] + D[3])) * invFact;
+                        const double coef = __builtin_amdgcn_mfma_f64_16x16x4f64(1.0, part, Z, 0, 0, 0)[0];
+                        double p = fmac_row_bcast<0>(0.0, coef, 1.0);
+                        p = (nb == 8) ? row_poly<8>(p, coef, 1.0, d) : (nb == 12) ? row_poly<12>(p, coef, 1.0, d)
+                                                                                     : row_poly<16>(p, coef, 1.0, d);
+                        const double val = p * exp2_tab64(slMid, d, e2tab);
+                        farMask |= 1u << cur;
+                        far0 = cur == 0 ? val : far0;
+                        far1 = cur == 1 ? val : far1;
+                        far2 = cur == 2 ? val : far2;
+                        far3 = cur == 3 ? val : far3;
+                        ++cur;
+                        if (cur <= uEnd) curEnd = far_count(chunk_of(i0 + cur));
+                    }
+                }
+                u = uEnd + 1;
+            }
+        }
+#else
         for (int u = 0; u < 4; ++u) {
             const int c = chunk_of(i0 + u);
             if (c >= nChunks) break;
@@ -790,6 +943,7 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
             far2 = u == 2 ? acc : far2;
             far3 = u == 3 ? acc : far3;
         }
+#endif
         MRC_PHASE(7);
         // ---- pass 2.  The per-line constants of the NEXT chunk are loaded while this one is computed (loop-carried,
         // so the global-load latency is never exposed between the loops of a chunk)
