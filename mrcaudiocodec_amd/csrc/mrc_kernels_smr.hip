@@ -443,9 +443,18 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
     // i + 1 runs on another die than block i.  Unit u below is chosen such that every XCD walks a CONTIGUOUS range of
     // (frame, signal) units: neighbouring frames share a hop, and the four signals of a joint frame share all their
     // samples -- with this order the second reader finds them in its own L2 instead of fetching them from HBM again.
-    const unsigned unit = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int64_t f = unit / nsig;
-    const int sig = unit % nsig;
+    // The four signals of a joint frame cost differently (the sweep skips what the M/S switch does not use), and the
+    // hardware deals consecutive workgroups to the shader engines round-robin: with sig = unit % 4 every engine would see
+    // ONE signal only and the kernel would wait for the engines with the expensive ones.  Rotating the signals from frame
+    // to frame gives every engine the same mix.
+    const unsigned slot = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int64_t f = slot / nsig;
+#ifdef MRC_SMR_NO_ROTATE
+    const int sig = slot % nsig;
+#else
+    const int sig = (int)((slot + f) % nsig);
+#endif
+    const unsigned unit = (unsigned)(f * nsig + sig);
     const int64_t off = offsets ? offsets[f] : f * stride;
     double2* A = (double2*)smem;                        // [H]
     double2* B = A + H;                                 // [H]
