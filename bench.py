@@ -263,6 +263,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1 << 17, help="mono frames per GPU per step")
+    ap.add_argument("--h2h-frames", type=int, default=0, help="frames of the host-to-host stream (0 = 4 x --frames)")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--skip-extras", action="store_true", help="only the headline measurement (profiling runs)")
     ap.add_argument("--only", choices=["stereo", "switch"], default=None,
@@ -414,15 +415,20 @@ def main():
 
         def pin(shape, dt):
             p = PinnedArray(shape, dt); keep.append(p); return p.array
-        Fh = F
+        # a stream of 4 F frames (SURVEY 8(d) C2 is 2^20): the pipeline's fill and drain (one chunk each) weigh less
+        Fh = args.h2h_frames or 4 * F
         host_pcm = pin(((Fh + 1) * HOP,), np.int16)
-        host_pcm[...] = pcm[:(Fh + 1) * HOP].cpu().numpy()
+        for f0 in range(0, Fh, F):                          # generated on the device slice by slice (counter-based)
+            nfr = min(F, Fh - f0)
+            (part,) = stream_slice(torch, device, "c2", f0, nfr)
+            host_pcm[f0 * HOP:(f0 + nfr + 1) * HOP] = part.cpu().numpy()
+            del part
         outs = dict(overall_scale=pin((Fh, 1), np.int32), scale_factor=pin((Fh, 1, NB), np.int32),
                     bit_alloc=pin((Fh, 1, NB), np.int32), mantissa=pin((Fh, 1, HOP), np.uint16),
                     reservoir_out=pin((Fh,), np.int32))
-        enc.h.encode_stream_pcm16(host_pcm, None, None, 0, outs)            # warm-up: lane buffers, first-touch
         runs = {}
-        for chunk in (2048, 4096, 8192, 16384):
+        for chunk in (16384, 32768, 65536):
+            enc.h.encode_stream_pcm16(host_pcm, None, None, chunk, outs)        # warm-up: lane buffers, first touch
             ts = []
             for _ in range(5):
                 t0 = time.perf_counter()
@@ -430,8 +436,9 @@ def main():
                 ts.append(time.perf_counter() - t0)
             runs[chunk] = float(np.median(ts))
         best = min(runs, key=runs.get)
-        dev_out = enc.encode_long(pcm[:(Fh + 1) * HOP].contiguous(), None, Fh, mantissa16=True)
-        same = bool(np.array_equal(dev_out["mantissa"].cpu().numpy().view(np.uint16), outs["mantissa"]))
+        nchk = min(F, Fh)
+        dev_out = enc.encode_long(pcm[:(nchk + 1) * HOP].contiguous(), None, nchk, mantissa16=True)
+        same = bool(np.array_equal(dev_out["mantissa"].cpu().numpy().view(np.uint16), outs["mantissa"][:nchk]))
         pcie = 2 * HOP + 2 * HOP + 2 * 4 * NB + 8
         line["host_to_host"] = {
             "value": round(Fh * HOP / runs[best] / 1e6, 3), "unit": "Msamples/s", "frames": Fh, "median_of": 5,
@@ -439,7 +446,10 @@ def main():
             "what": "int16 PCM in page-locked host memory -> H2D -> kernels -> D2H -> uint16 mantissas + int32 side info "
                     "in page-locked host memory (mrc_encode_stream_pcm16, 3 HIP streams)",
             "pcie_bytes_per_frame": pcie, "pcie_GBs_each_way": round(Fh * 2 * HOP / runs[best] / 1e9, 2),
+            "pcie_ceiling": "page-locked copies on this box (tools/pcie_rates.py): 55-57 GB/s one way alone, 25 / 47 GB/s "
+                            "each way with both directions busy at 16 / 64 MiB per copy",
             "equals_resident_result": same}
+        del dev_out
         for p in keep:
             p.free()
 

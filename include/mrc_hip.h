@@ -119,8 +119,10 @@ int mrc_encode_joint_blocks(mrc_handle* h, int64_t n_blocks, const double* left,
  * are converted on load exactly as pcmfile.py:91-100 does (x = 2c/65535 correctly rounded, -32768 -> 0.0).
  * Frames are independent given reservoir_in [n] (NULL = zeros).  Outputs as mrc_encode_mono / _joint for a = b = L,
  * except the mantissa plane, which is uint16 [n][streams][L] (codes are at most 16 bits wide, codecThem.py:292-293).
- * The work is cut into chunks of chunk_frames frames (0: 16384); chunk i's upload, kernels and download are queued
- * on one of three HIP streams, so the copies of neighbouring chunks run beside its kernels.  With host buffers from
+ * The work is cut into chunks of chunk_frames frames (0: 32 768, fewer for streams shorter than six chunks) over a
+ * ring of three chunk buffers; ALL uploads are queued on one HIP stream, all kernels on the handle's stream, all
+ * downloads on a third, ordered by events, so chunk i+1 is copied in and chunk i-1 copied out beside chunk i's
+ * kernels (one stream per direction: what the copy engines of the MI355X box run fastest).  With host buffers from
  * mrc_host_alloc / mrc_host_register (page-locked) the copies are truly asynchronous; pageable buffers work, slower.
  * PCIe bytes per (frame, channel): 2 048 in, 2 048 + 2 * 4 * nBands + 8 (+ 4 * nBands per joint frame) out. */
 int mrc_encode_stream_pcm16(mrc_handle* h, int64_t n_frames, const int16_t* pcm_left, const int16_t* pcm_right,

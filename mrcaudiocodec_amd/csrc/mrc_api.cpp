@@ -40,17 +40,19 @@ struct Workspace {
     void release() { lines.release(); smr.release(); peak.release(); }
 };
 
-// one lane of the pipelined host entry points: a stream with its own inputs, workspace and outputs, so that the
-// H2D copy of chunk i+1 and the D2H copy of chunk i-1 run beside the kernels of chunk i
+// The pipelined host entry point runs THREE streams -- one that only copies in, one that only launches kernels, one that
+// only copies out -- over a ring of chunk buffers (lanes), ordered by events: measured on the MI355X box, page-locked
+// copies reach 42-48 GB/s each way with ONE stream per direction and drop to 19-25 GB/s with three streams that each
+// copy both ways (tools/pcie_rates.py), which is what one-stream-per-chunk pipelining amounts to.
 struct Lane {
-    hipStream_t st = nullptr;
-    Workspace ws;
     DevBuf pcmL, pcmR, resIn, oScale, ms, ba, sf, mant, resOut;
+    hipEvent_t evIn = nullptr, evK = nullptr, evOut = nullptr;   // chunk copied in / encoded / copied out
     void release() {
-        ws.release();
         for (DevBuf* b : {&pcmL, &pcmR, &resIn, &oScale, &ms, &ba, &sf, &mant, &resOut}) b->release();
-        if (st) (void)hipStreamDestroy(st);
-        st = nullptr;
+        for (hipEvent_t* e : {&evIn, &evK, &evOut}) {
+            if (*e) (void)hipEventDestroy(*e);
+            *e = nullptr;
+        }
     }
 };
 constexpr int kLanes = 3;
@@ -63,7 +65,12 @@ struct mrc_handle {
     std::map<std::pair<int, int>, HostShape> shapes;
     std::string error;
     Workspace ws;                    // workspace of mrc_dev_encode* (calls on one handle are serialised)
-    Lane lanes[kLanes];              // mrc_encode_stream_pcm16
+    Lane lanes[kLanes];              // mrc_encode_stream_pcm16: chunk buffers ...
+    hipStream_t stIn = nullptr, stOut = nullptr;   // ... and its copy-in / copy-out streams; the kernels of all chunks run
+    Workspace wsPipe;                //     on `stream`, one after the other: one workspace.  (No third stream of its own:
+                                     //     the runtime multiplexes streams onto 4 hardware queues by default -- with the
+                                     //     null stream and `stream` that is exactly four; a fifth would share a queue with
+                                     //     one of the others and serialise with it: 10 000 instead of 19 000 Msamples/s)
     // staging of the host entry points
     DevBuf inL, inR, inAux, inAux2, inAux3, outA, outB, outC, outD, outE, outF, outG;
     bool timing = false;
@@ -176,10 +183,12 @@ void mrc_destroy(mrc_handle* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& kv : h->shapes) free_shape(&kv.second);
-    for (auto& lane : h->lanes) {
-        if (lane.st) (void)hipStreamSynchronize(lane.st);
-        lane.release();
+    for (hipStream_t* st : {&h->stIn, &h->stOut}) {
+        if (*st) { (void)hipStreamSynchronize(*st); (void)hipStreamDestroy(*st); }
+        *st = nullptr;
     }
+    for (auto& lane : h->lanes) lane.release();
+    h->wsPipe.release();
     h->ws.release();
     for (DevBuf* b : {&h->inL, &h->inR, &h->inAux, &h->inAux2, &h->inAux3,
                       &h->outA, &h->outB, &h->outC, &h->outD, &h->outE, &h->outF, &h->outG})
@@ -512,12 +521,20 @@ int mrc_encode_stream_pcm16(mrc_handle* h, int64_t n_frames, const int16_t* pcm_
     MRC_TRY(get_shape(h, L, L, &hs));
     const DevShape& S = hs->dev;
     const int joint = pcm_right ? 1 : 0, nsig = joint ? 4 : 1, nstream = joint ? 2 : 1;
-    int64_t chunk = chunk_frames ? chunk_frames : 16384;
+    // default chunk: 32 768 frames (64 MiB each way: below that the fixed cost of a copy shows -- 9 000 Msamples/s at
+    // 8 192 frames against 19 000 at 32 768), halved while the stream has fewer than six chunks to pipeline
+    int64_t chunk = chunk_frames;
+    if (!chunk)
+        for (chunk = 32768; chunk > 8192 && n_frames < 6 * chunk;) chunk /= 2;
     if (chunk > n_frames) chunk = n_frames;
-    // lanes: created on first use, buffers sized for one chunk (+ the one-hop halo in front of it)
+    // streams, events and chunk buffers: created on first use, buffers sized for one chunk (+ the one-hop halo in front)
+    for (hipStream_t* st : {&h->stIn, &h->stOut})
+        if (!*st) MRC_HIP(h, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    const hipStream_t stK = h->stream;
     const size_t szPcm = (size_t)(chunk + 1) * L * sizeof(int16_t);
     for (auto& lane : h->lanes) {
-        if (!lane.st) MRC_HIP(h, hipStreamCreateWithFlags(&lane.st, hipStreamNonBlocking));
+        for (hipEvent_t* e : {&lane.evIn, &lane.evK, &lane.evOut})
+            if (!*e) MRC_HIP(h, hipEventCreateWithFlags(e, hipEventDisableTiming));
         MRC_HIP(h, lane.pcmL.reserve(szPcm));
         if (joint) MRC_HIP(h, lane.pcmR.reserve(szPcm));
         MRC_HIP(h, lane.resIn.reserve((size_t)chunk * sizeof(int32_t)));
@@ -527,48 +544,58 @@ int mrc_encode_stream_pcm16(mrc_handle* h, int64_t n_frames, const int16_t* pcm_
         MRC_HIP(h, lane.sf.reserve((size_t)chunk * nstream * S.nBands * sizeof(int32_t)));
         MRC_HIP(h, lane.mant.reserve((size_t)chunk * nstream * S.halfN * sizeof(uint16_t)));
         MRC_HIP(h, lane.resOut.reserve((size_t)chunk * sizeof(int32_t)));
-        MRC_HIP(h, lane.ws.lines.reserve((size_t)chunk * nsig * S.halfN * sizeof(double)));
-        MRC_HIP(h, lane.ws.smr.reserve((size_t)chunk * nsig * S.nBands * sizeof(double)));
-        MRC_HIP(h, lane.ws.peak.reserve(alloc_workspace_bytes(S, chunk, joint)));
     }
+    MRC_HIP(h, h->wsPipe.lines.reserve((size_t)chunk * nsig * S.halfN * sizeof(double)));
+    MRC_HIP(h, h->wsPipe.smr.reserve((size_t)chunk * nsig * S.nBands * sizeof(double)));
+    MRC_HIP(h, h->wsPipe.peak.reserve(alloc_workspace_bytes(S, chunk, joint)));
     struct DrainAll {                       // whichever way we leave: nothing of ours is still using the caller's memory
         mrc_handle* h;
-        ~DrainAll() { for (auto& lane : h->lanes) if (lane.st) (void)hipStreamSynchronize(lane.st); }
+        ~DrainAll() { for (hipStream_t st : {h->stIn, h->stream, h->stOut}) if (st) (void)hipStreamSynchronize(st); }
     } drain{h};
     const bool wasTiming = h->timing;
-    h->timing = false;                      // the per-kernel events of encode_core belong to ONE stream
+    h->timing = false;                      // the per-kernel events of encode_core belong to ONE call at a time
     int rc = MRC_OK;
     int64_t c = 0;
     for (int64_t f0 = 0; f0 < n_frames && rc == MRC_OK; f0 += chunk, ++c) {
         Lane& lane = h->lanes[c % kLanes];
+        const bool reused = c >= kLanes;    // the lane's events still stand for chunk c - kLanes when they are waited on here
         const int64_t n = (n_frames - f0 < chunk) ? n_frames - f0 : chunk;
-        hipStream_t st = lane.st;
-        // everything queued on lane.st is ordered behind the lane's previous chunk: its buffers are free again
         const size_t inBytes = (size_t)(n + 1) * L * sizeof(int16_t);
 #define MRC_Q(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = hip_fail(h, e_, #call); break; } } while (0)
         do {
-            MRC_Q(hipMemcpyAsync(lane.pcmL.p, pcm_left + f0 * L, inBytes, hipMemcpyHostToDevice, st));
-            if (joint) MRC_Q(hipMemcpyAsync(lane.pcmR.p, pcm_right + f0 * L, inBytes, hipMemcpyHostToDevice, st));
+            // copy in (the lane's input buffers are free once the kernels of its previous chunk have run)
+            if (reused) MRC_Q(hipStreamWaitEvent(h->stIn, lane.evK, 0));
+            MRC_Q(hipMemcpyAsync(lane.pcmL.p, pcm_left + f0 * L, inBytes, hipMemcpyHostToDevice, h->stIn));
+            if (joint) MRC_Q(hipMemcpyAsync(lane.pcmR.p, pcm_right + f0 * L, inBytes, hipMemcpyHostToDevice, h->stIn));
             if (reservoir_in)
-                MRC_Q(hipMemcpyAsync(lane.resIn.p, reservoir_in + f0, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+                MRC_Q(hipMemcpyAsync(lane.resIn.p, reservoir_in + f0, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stIn));
+            MRC_Q(hipEventRecord(lane.evIn, h->stIn));
+            // kernels (the lane's output buffers are free once its previous chunk has been copied out)
+            MRC_Q(hipStreamWaitEvent(stK, lane.evIn, 0));
+            if (reused) MRC_Q(hipStreamWaitEvent(stK, lane.evOut, 0));
             rc = encode_core(h, S, n, lane.pcmL.p, joint ? lane.pcmR.p : nullptr, kSampleI16, L, nullptr,
                              reservoir_in ? lane.resIn.as<int32_t>() : nullptr, lane.oScale.as<int32_t>(),
                              lane.ms.as<int32_t>(), lane.ba.as<int32_t>(), lane.sf.as<int32_t>(), lane.mant.p,
-                             MRC_MANTISSA_I16, lane.resOut.as<int32_t>(), nullptr, lane.ws, st);
+                             MRC_MANTISSA_I16, lane.resOut.as<int32_t>(), nullptr, h->wsPipe, stK);
             if (rc != MRC_OK) break;
-            MRC_Q(hipMemcpyAsync(overall_scale + f0 * nsig, lane.oScale.p, (size_t)n * nsig * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            MRC_Q(hipEventRecord(lane.evK, stK));
+            // copy out
+            hipStream_t so = h->stOut;
+            MRC_Q(hipStreamWaitEvent(so, lane.evK, 0));
+            MRC_Q(hipMemcpyAsync(mantissa16 + f0 * nstream * S.halfN, lane.mant.p, (size_t)n * nstream * S.halfN * sizeof(uint16_t), hipMemcpyDeviceToHost, so));
+            MRC_Q(hipMemcpyAsync(overall_scale + f0 * nsig, lane.oScale.p, (size_t)n * nsig * sizeof(int32_t), hipMemcpyDeviceToHost, so));
             if (joint)
-                MRC_Q(hipMemcpyAsync(ms_switch + f0 * S.nBands, lane.ms.p, (size_t)n * S.nBands * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            MRC_Q(hipMemcpyAsync(bit_alloc + f0 * nstream * S.nBands, lane.ba.p, (size_t)n * nstream * S.nBands * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            MRC_Q(hipMemcpyAsync(scale_factor + f0 * nstream * S.nBands, lane.sf.p, (size_t)n * nstream * S.nBands * sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            MRC_Q(hipMemcpyAsync(mantissa16 + f0 * nstream * S.halfN, lane.mant.p, (size_t)n * nstream * S.halfN * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
-            MRC_Q(hipMemcpyAsync(reservoir_out + f0, lane.resOut.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                MRC_Q(hipMemcpyAsync(ms_switch + f0 * S.nBands, lane.ms.p, (size_t)n * S.nBands * sizeof(int32_t), hipMemcpyDeviceToHost, so));
+            MRC_Q(hipMemcpyAsync(bit_alloc + f0 * nstream * S.nBands, lane.ba.p, (size_t)n * nstream * S.nBands * sizeof(int32_t), hipMemcpyDeviceToHost, so));
+            MRC_Q(hipMemcpyAsync(scale_factor + f0 * nstream * S.nBands, lane.sf.p, (size_t)n * nstream * S.nBands * sizeof(int32_t), hipMemcpyDeviceToHost, so));
+            MRC_Q(hipMemcpyAsync(reservoir_out + f0, lane.resOut.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, so));
+            MRC_Q(hipEventRecord(lane.evOut, so));
         } while (0);
 #undef MRC_Q
     }
     h->timing = wasTiming;
     if (rc != MRC_OK) return rc;
-    for (auto& lane : h->lanes) MRC_HIP(h, hipStreamSynchronize(lane.st));
+    for (hipStream_t st : {h->stIn, stK, h->stOut}) MRC_HIP(h, hipStreamSynchronize(st));
     return MRC_OK;
 }
 
