@@ -203,9 +203,10 @@ __global__ __launch_bounds__(kWave) void quantize_kernel(DevShape S, int joint, 
                                                          const double* __restrict__ bandPeak,
                                                          const int* __restrict__ msSwitch,
                                                          const int* __restrict__ bitAlloc,
-                                                         int* __restrict__ scaleFactor, OutT* __restrict__ mantissa) {
-    __shared__ int sBa[kMaxBands], sSf[kMaxBands], sSig[kMaxBands], sOsc[kMaxBands];
-    __shared__ unsigned char sBand[kBandLds];            // band of every line (copy of S.bandOfLine)
+                                                         int* __restrict__ scaleFactor, OutT* __restrict__ mantissa,
+                                                         int vecOk /* lines and mantissa planes 16-byte aligned */) {
+    __shared__ unsigned int sInfo[kMaxBands];            // per band: bits | scale factor << 8 | overall scale << 16 | signal << 24
+    __shared__ __attribute__((aligned(4))) unsigned char sBand[kBandLds];   // band of every line (copy of S.bandOfLine)
     const int lane = threadIdx.x;
     const int nstream = joint ? 2 : 1, nsig = joint ? 4 : 1;
     const int64_t f = blockIdx.x / nstream;
@@ -226,32 +227,63 @@ __global__ __launch_bounds__(kWave) void quantize_kernel(DevShape S, int joint, 
         // scaling by 2^overallScale is exact, so max and scale commute
         const double peak = ldexp(bandPeak[(f * nsig + sig) * nb + lane], osc[sig]);
         const int sf = scale_factor_dev(peak, S.nScaleBits, ba);
-        sBa[lane] = ba;
-        sSf[lane] = sf;
-        sSig[lane] = sig;
-        sOsc[lane] = osc[sig];
+        sInfo[lane] = (unsigned)ba | ((unsigned)sf << 8) | ((unsigned)osc[sig] << 16) | ((unsigned)sig << 24);
         scaleFactor[(f * nstream + strm) * nb + lane] = sf;
     }
     __syncthreads();
     OutT* out = mantissa + (f * nstream + strm) * M;
-    constexpr int kBatch = 4;                            // lines in flight per lane
-    for (int k0 = lane; k0 < M; k0 += kWave * kBatch) {
-        int bnd[kBatch], sc[kBatch];
-        double x[kBatch];
+    auto code_of = [&](double x, unsigned info) -> OutT {   // codecThem.py:348-349
+        const int ba = (int)(info & 0xff);
+        return (OutT)(ba ? mantissa_dev(ldexp(x, (int)((info >> 16) & 0xff)), (int)((info >> 8) & 0xff), S.nScaleBits, ba) : 0);
+    };
+    if (vecOk && bandInLds && !(M & 3)) {
+        // a lane takes FOUR CONSECUTIVE lines: one LDS word for their bands, 32 contiguous bytes of lines (one signal: the
+        // four lines of a lane lie in one band almost always), one 8- or 16-byte store of the four codes
+        for (int k = 4 * lane; k < M; k += 4 * kWave) {
+            const unsigned bands = *reinterpret_cast<const unsigned int*>(sBand + k);
+            unsigned info[4];
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-            const int k = min(k0 + u * kWave, M - 1);
-            bnd[u] = bandInLds ? sBand[k] : S.bandOfLine[k];
-            const int sg = sSig[bnd[u]];
-            sc[u] = sOsc[bnd[u]];
-            x[u] = sBa[bnd[u]] ? X[sg * M + k] : 0.0;       // lines of bands without bits are not even read
+            for (int u = 0; u < 4; ++u) info[u] = sInfo[(bands >> (8 * u)) & 0xff];
+            double x[4] = {0.0, 0.0, 0.0, 0.0};
+            const bool anyBits = ((info[0] | info[1] | info[2] | info[3]) & 0xff) != 0;   // lines of bands without bits are not read
+            const bool oneSignal = ((info[0] ^ info[3]) >> 24) == 0 && ((info[1] ^ info[2]) >> 24) == 0 && ((info[0] ^ info[1]) >> 24) == 0;
+            if (anyBits) {
+                if (oneSignal) {
+                    const double* src = X + (int64_t)(info[0] >> 24) * M + k;
+                    const double2 p = *reinterpret_cast<const double2*>(src), q = *reinterpret_cast<const double2*>(src + 2);
+                    x[0] = p.x; x[1] = p.y; x[2] = q.x; x[3] = q.y;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[u] = X[(int64_t)(info[u] >> 24) * M + k + u];
+                }
+            }
+            OutT c[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) c[u] = code_of(x[u], info[u]);
+            if (sizeof(OutT) == 2) {
+                uint2 w;
+                w.x = (unsigned)(unsigned short)c[0] | ((unsigned)(unsigned short)c[1] << 16);
+                w.y = (unsigned)(unsigned short)c[2] | ((unsigned)(unsigned short)c[3] << 16);
+                *reinterpret_cast<uint2*>(out + k) = w;
+            } else {
+                *reinterpret_cast<int4*>(out + k) = make_int4((int)c[0], (int)c[1], (int)c[2], (int)c[3]);
+            }
         }
+    } else {
+        constexpr int kBatch = 4;                        // lines in flight per lane
+        for (int k0 = lane; k0 < M; k0 += kWave * kBatch) {
+            unsigned info[kBatch];
+            double x[kBatch];
 #pragma unroll
-        for (int u = 0; u < kBatch; ++u) {
-            const int k = k0 + u * kWave;
-            if (k < M) {
-                const int ba = sBa[bnd[u]];
-                out[k] = (OutT)(ba ? mantissa_dev(ldexp(x[u], sc[u]), sSf[bnd[u]], S.nScaleBits, ba) : 0);   // codecThem.py:348-349
+            for (int u = 0; u < kBatch; ++u) {
+                const int k = min(k0 + u * kWave, M - 1);
+                info[u] = sInfo[bandInLds ? sBand[k] : S.bandOfLine[k]];
+                x[u] = (info[u] & 0xff) ? X[(int64_t)(info[u] >> 24) * M + k] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int k = k0 + u * kWave;
+                if (k < M) out[k] = code_of(x[u], info[u]);
             }
         }
     }
@@ -287,12 +319,13 @@ hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, con
     hipLaunchKernelGGL(bitalloc_kernel, dim3((unsigned)((nFrames + fpw - 1) / fpw)), dim3(kWave), lds, st, S, joint,
                        nFrames, fpw, smr, msSwitch, resIn, bitAlloc, resOut);
     if (ev) (void)hipEventRecord(ev[1], st);
+    const int vecOk = !((reinterpret_cast<uintptr_t>(lines) | reinterpret_cast<uintptr_t>(mantissa)) & 15);
     if (mantFmt == MRC_MANTISSA_I16)
         hipLaunchKernelGGL(quantize_kernel<unsigned short>, dim3((unsigned)(nFrames * (joint ? 2 : 1))), dim3(kWave), 0, st, S, joint,
-                           lines, oscale, bandPeakWs, msSwitch, bitAlloc, scaleFactor, (unsigned short*)mantissa);
+                           lines, oscale, bandPeakWs, msSwitch, bitAlloc, scaleFactor, (unsigned short*)mantissa, vecOk);
     else
         hipLaunchKernelGGL(quantize_kernel<int>, dim3((unsigned)(nFrames * (joint ? 2 : 1))), dim3(kWave), 0, st, S, joint,
-                           lines, oscale, bandPeakWs, msSwitch, bitAlloc, scaleFactor, (int*)mantissa);
+                           lines, oscale, bandPeakWs, msSwitch, bitAlloc, scaleFactor, (int*)mantissa, vecOk);
     return hipGetLastError();
 }
 
