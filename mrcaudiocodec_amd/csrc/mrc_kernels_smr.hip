@@ -246,12 +246,24 @@ template <int J, int NB>
 __device__ __forceinline__ double far_group(const double* __restrict__ mt, int nFar, double cq, double slMid,
                                             double d, int lane, const double* __restrict__ e2tab) {
     double B[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) B[j] = 0.0;
-    for (int m = lane; m < nFar; m += kWave) {
+    // the first 64 maskers initialise the sums: every lane takes part, a lane past nFar (>= 1) with a zero term
+    {
+        const int m = min(lane, nFar - 1);
         const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
-        double term = I * exp2_tab64(sl, cq - zm, e2tab);                   // cq - zm > 0 for m < nFar
-        const double da = (sl - slMid) * (0.6931471805599453094 / kExpTabD);   // slope offset in nats per Bark
+        double term = (lane < nFar) ? I * exp2_tab64(sl, cq - zm, e2tab) : 0.0;   // cq - zm > 0 for m < nFar
+        const double da = (sl - slMid) * (0.6931471805599453094 / kExpTabD);       // slope offset in nats per Bark
+#pragma unroll
+        for (int j = 0; j <= J; ++j) {
+            B[j] = term;
+            term *= da;
+        }
+#pragma unroll
+        for (int j = J + 1; j < NB; ++j) B[j] = 0.0;
+    }
+    for (int m = lane + kWave; m < nFar; m += kWave) {
+        const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
+        double term = I * exp2_tab64(sl, cq - zm, e2tab);
+        const double da = (sl - slMid) * (0.6931471805599453094 / kExpTabD);
 #pragma unroll
         for (int j = 0; j <= J; ++j) {
             B[j] += term;
@@ -919,11 +931,12 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
             const int kFirst = c * kWave;
             const double zFirst = S.zb[kFirst], zLast = S.zb[min(kFirst + kWave - 1, M - 1)];
             const double zHalfEnd = S.zb[min(kFirst + kWave / 2 - 1, M - 1)], zHalfBeg = S.zb[min(kFirst + kWave / 2, M - 1)];
-            const double need1 = spreadHalf * (0.5 * (zLast - zFirst));
-            const double need2 = spreadHalf * (0.5 * fmax(zHalfEnd - zFirst, zLast - zHalfBeg));
-            double need = need1;
+            double need = spreadHalf * (0.5 * (zLast - zFirst));
             int nGroups = 1;
-            if (need1 > kFarLimitMax) { need = need2; nGroups = 2; }
+            if (need > kFarLimitMax) {                     // (wave-uniform)
+                need = spreadHalf * (0.5 * fmax(zHalfEnd - zFirst, zLast - zHalfBeg));
+                nGroups = 2;
+            }
             const int order = need <= kFarLimit8 ? 8 : need <= kFarLimit12 ? 12 :
                               (MRC_FAR_MAX_ORDER >= 16 && need <= kFarLimit16) ? 16 :
                               (MRC_FAR_MAX_ORDER >= 20 && need <= kFarLimit20) ? 20 : 0;
