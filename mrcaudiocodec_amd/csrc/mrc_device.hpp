@@ -172,6 +172,23 @@ template <> __device__ __forceinline__ void butterfly<4>(double2* u) {
     u[3] = make_double2(b.x - d.y, b.y + d.x);
 }
 
+template <> __device__ __forceinline__ void butterfly<8>(double2* u) {
+    const double h = 0.70710678118654752440;
+    auto add = [](double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); };
+    auto sub = [](double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); };
+    const double2 a0 = add(u[0], u[4]), a1 = add(u[1], u[5]), a2 = add(u[2], u[6]), a3 = add(u[3], u[7]);
+    const double2 b0 = sub(u[0], u[4]);
+    double2 b1 = sub(u[1], u[5]), b2 = sub(u[2], u[6]), b3 = sub(u[3], u[7]);
+    b1 = make_double2(h * (b1.x + b1.y), h * (b1.y - b1.x));          // * (1 - i)/sqrt2
+    b2 = make_double2(b2.y, -b2.x);                                   // * (-i)
+    b3 = make_double2(h * (b3.y - b3.x), -h * (b3.x + b3.y));         // * (-1 - i)/sqrt2
+    double2 e[4] = {a0, a1, a2, a3}, o[4] = {b0, b1, b2, b3};
+    butterfly<4>(e);
+    butterfly<4>(o);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { u[2 * q] = e[q]; u[2 * q + 1] = o[q]; }
+}
+
 // Twiddle source of the block FFT.  TwGlobal: the full table exp(-2 pi i t/n) in global memory (any n).
 // TwQuarter: its first quadrant staged in LDS, n a power of two: w(s + q n/4) = w(s) (-i)^q -- same values, but no
 // global-load latency inside the passes (the FFT of a block is a chain of dependent, barrier-separated passes).
@@ -248,6 +265,9 @@ __device__ __forceinline__ double2* fft_lds_pow2(double2* A, double2* B, int n, 
     for (int s = 0; s < nrad; ++s) {
         const int R = rad[s];
         if (R == 4) fft_pass<4, true, TwQuarter, NT>(A, B, n, p, W, tid);
+#ifdef MRC_SMR_FFT8
+        else if (R == 8) fft_pass<8, true, TwQuarter, NT>(A, B, n, p, W, tid);
+#endif
         else fft_pass<2, true, TwQuarter, NT>(A, B, n, p, W, tid);
         __syncthreads();
         double2* t = A; A = B; B = t;
