@@ -105,7 +105,7 @@ def measured_valu(smr_ms, frames):
         return None
     fr = float(d.get("frames_per_launch", 1))
     out = {"valu_insts_per_frame": k["valu_insts_per_frame"], "issue_frac_of_peak": k.get("valu_issue_frac_at_4cyc"),
-           "source": name}
+           "valu_busy_frac": k.get("valu_busy_frac"), "source": name}
     if all(c in k for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU")):
         f64_insts = k["SQ_INSTS_VALU_ADD_F64"] + k["SQ_INSTS_VALU_MUL_F64"] + k["SQ_INSTS_VALU_FMA_F64"]
         flops_per_frame = (k["SQ_INSTS_VALU_ADD_F64"] + k["SQ_INSTS_VALU_MUL_F64"] + 2 * k["SQ_INSTS_VALU_FMA_F64"]) * 64 / fr

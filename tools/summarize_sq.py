@@ -34,5 +34,8 @@ for k, c in kern.items():
         c["valu_insts_per_frame"] = round(c["SQ_INSTS_VALU"] / frames, 1)
         if "GRBM_GUI_ACTIVE" in c:
             c["valu_issue_frac_at_4cyc"] = round(c["SQ_INSTS_VALU"] * 4 / (c["GRBM_GUI_ACTIVE"] / 8 * 1024), 3)
+    if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+        # SQ_ACTIVE_INST_VALU counts quad-cycles with a VALU instruction executing, summed over the 1024 SIMDs
+        c["valu_busy_frac"] = round(c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (c["GRBM_GUI_ACTIVE"] / 8), 3)
 json.dump({"frames_per_launch": frames, "kernels": kern}, open(os.path.join(root, tag + "_sq_counters.json"), "w"), indent=1)
 print(json.dumps(kern.get("smr_kernel", {}), indent=1))
