@@ -286,6 +286,22 @@ int mrc_huffman_gain(mrc_handle* h, int64_t n_blocks, int a, int b, int n_stream
 int mrc_dev_huffman_gain(mrc_handle* h, int a, int b, int64_t n_frames, int n_streams, const int32_t* bit_alloc,
                          const int32_t* mantissa, const int32_t* reservoir_out, int32_t* huff_table,
                          int32_t* bits_saved, int32_t* reservoir_next, void* stream);
+/* The `.pac` chunks of n_blocks blocks of ONE shape, packed ON THE DEVICE: the bytes WriteDataBlock /
+ * JointWriteDataBlock append per block (pacfileThem.py:652-781, 825-963; bitpack.py:36-101; the Huffman choice
+ * and recoding of codecThem.py:136-203) -- byte for byte what mrc_pack_blocks_ex writes on the host, from the
+ * encoder's outputs where mrc_dev_encode* left them.  All array arguments are DEVICE pointers, layouts as
+ * mrc_pack_blocks_ex: overall_scale [n][joint ? 4 : n_channels], ms_switch [n][nBands] (joint), scale_factor /
+ * bit_alloc [n][n_channels][nBands], mantissa [n][n_channels][(a+b)/2] (MRC_MANTISSA_I32 / _I16), huff_table_in
+ * [n * n_channels] or NULL (NULL: priced here if use_huffman, else raw).  out [out_cap] receives the chunks
+ * (4-byte length + payload each), block_offset [n + 1] the byte offset of every block (last entry: the total);
+ * huff_table / bits_saved [n * n_channels] may be NULL.  total_bytes (HOST pointer) non-NULL: the call waits for
+ * the stream and returns the total, MRC_ERR_NOMEM if it exceeds out_cap (nothing is written past out_cap; size
+ * the buffer with mrc_pack_bound); NULL: fully asynchronous, read block_offset[n] later. */
+int mrc_dev_pack_blocks(mrc_handle* h, int a, int b, int64_t n_blocks, int n_channels, int joint, int use_huffman,
+                        const int32_t* huff_table_in, const int32_t* overall_scale, const int32_t* ms_switch,
+                        const int32_t* scale_factor, const int32_t* bit_alloc, const void* mantissa, int mantissa_format,
+                        uint8_t* out, int64_t out_cap, int64_t* block_offset, int32_t* huff_table, int32_t* bits_saved,
+                        int64_t* total_bytes, void* stream);
 
 /* ---- decode side ("next" row f-4: the reference's decoder, pacfileThem.py:130-585 + codecThem.py:30-134) ----
  * Host: header and chunk parsing (no GPU, no handle).  Device: dequantise -> undo the overall scale -> M/S

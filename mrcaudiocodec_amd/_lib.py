@@ -100,6 +100,8 @@ def _load():
         "mrc_get_kernel_ms": (C.c_int, [H, _f64p]),
         "mrc_huffman_gain": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i32p]),
         "mrc_dev_huffman_gain": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_int] + [C.c_void_p] * 7),
+        "mrc_dev_pack_blocks": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 +
+                                [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, _i64p, C.c_void_p]),
         "mrc_pac_read_header": (C.c_int, [_u8p, C.c_int64, C.POINTER(MrcConfig), _i32p, C.POINTER(C.c_uint32), _i64p]),
         "mrc_pac_scan_chunks": (C.c_int64, [_u8p, C.c_int64, C.c_int64, _i64p, C.c_int64]),
         "mrc_unpack_blocks": (C.c_int, [C.POINTER(MrcConfig), C.c_int64, C.c_int, C.c_int, _u8p, C.c_int64, _i64p] +
@@ -419,6 +421,18 @@ class Handle:
                          reservoir_next=None, stream=None):
         self._check(lib.mrc_dev_huffman_gain(self._h, a, b, n_frames, n_streams, bit_alloc, mantissa, reservoir_out,
                                              huff_table, bits_saved, reservoir_next, stream))
+
+    def dev_pack_blocks(self, a, b, n_blocks, n_channels, joint, use_huffman, huff_table_in, overall_scale, ms_switch,
+                        scale_factor, bit_alloc, mantissa, mantissa16, out, out_cap, block_offset, huff_table=None,
+                        bits_saved=None, want_total=True, stream=None):
+        """`.pac` chunks packed on the device (mrc_dev_pack_blocks): every array argument is a DEVICE address.  -> total
+        bytes (want_total: waits for the stream), else None."""
+        total = np.zeros(1, np.int64)
+        self._check(lib.mrc_dev_pack_blocks(self._h, a, b, n_blocks, n_channels, 1 if joint else 0, 1 if use_huffman else 0,
+                                            huff_table_in, overall_scale, ms_switch, scale_factor, bit_alloc, mantissa,
+                                            1 if mantissa16 else 0, out, out_cap, block_offset, huff_table, bits_saved,
+                                            total.ctypes.data_as(_i64p) if want_total else None, stream))
+        return int(total[0]) if want_total else None
 
     # ---- decode side
     def decode(self, a, b, overall_scale, scale_factor, bit_alloc, mantissa, ms_switch=None):

@@ -72,6 +72,38 @@ class StreamEncoder:
         L = self.h.cfg.n_mdct_lines
         return self.encode(L, L, left, right, n_frames, L, None, reservoir_in, mantissa16=mantissa16)
 
+    def pack(self, a, b, out, use_huffman=True, huff_table=None, typical_bytes=None):
+        """`.pac` chunks of the blocks in `out` (a dict from encode), packed ON THE DEVICE (mrc_dev_pack_blocks): the bytes
+        pacfileThem.py's WriteDataBlock / JointWriteDataBlock append, block after block.  huff_table: device tensor of
+        table ids already chosen (huffman_gain), else priced here (or raw).  -> dict of device tensors: bytes (uint8, the
+        used prefix of the buffer), block_offset [n + 1] int64, huff_table, bits_saved [n][nStreams]."""
+        from . import _lib
+        n, ns = out["bit_alloc"].shape[0], out["bit_alloc"].shape[1]
+        joint = out["overall_scale"].shape[-1] == 4 and ns == 2
+        m16 = out["mantissa"].dtype == torch.int16
+        cfg = self.h.cfg
+        bound = int(_lib.lib.mrc_pack_bound(_lib.C.byref(cfg), int(a), int(b), 1, 1 if joint else 0))
+        i32 = dict(dtype=torch.int32, device=self.device)
+        table, saved = torch.empty((n, ns), **i32), torch.empty((n, ns), **i32)
+        offs = torch.empty((n + 1,), dtype=torch.int64, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        # a first buffer sized for the typical chunk (a block of 1024 lines at 128 kb/s/ch is ~350 bytes per channel), the
+        # worst case (every line 16 raw bits behind the longest escape code) only if that turns out too small
+        cap = n * ns * (typical_bytes or max(64, (a + b) // 2)) + 4096
+        for attempt in (0, 1):
+            buf = torch.empty((cap,), dtype=torch.uint8, device=self.device)
+            try:
+                total = self.h.dev_pack_blocks(a, b, n, ns, joint, use_huffman, _ptr(huff_table), _ptr(out["overall_scale"]),
+                                               _ptr(out["ms_switch"]) if joint else None, _ptr(out["scale_factor"]),
+                                               _ptr(out["bit_alloc"]), _ptr(out["mantissa"]), m16, _ptr(buf), cap, _ptr(offs),
+                                               _ptr(table), _ptr(saved), True, stream)
+                break
+            except _lib.MrcError:
+                if attempt or cap >= n * ns * bound:
+                    raise
+                cap = n * ns * bound
+        return {"bytes": buf[:total], "block_offset": offs, "huff_table": table, "bits_saved": saved}
+
     def huffman_gain(self, a, b, out, use_huffman=True):
         """Prices the Huffman tables for the blocks in `out` (a dict from encode) on the device and returns
         (huff_table [n][nStreams], bits_saved [n][nStreams], reservoir_next [n]) -- codecThem.py:136-203,224,274."""

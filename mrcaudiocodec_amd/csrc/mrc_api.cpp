@@ -73,6 +73,7 @@ struct mrc_handle {
                                      //     one of the others and serialise with it: 10 000 instead of 19 000 Msamples/s)
     // staging of the host entry points
     DevBuf inL, inR, inAux, inAux2, inAux3, outA, outB, outC, outD, outE, outF, outG;
+    DevBuf packWs;                   // mrc_dev_pack_blocks: chunk sizes / positions / (table ids)
     bool timing = false;
     bool exactSpread = false;        // mrc_set_option(MRC_OPT_EXACT_SPREAD)
     bool smrAllBands = false;        // mrc_set_option(MRC_OPT_SMR_ALL_BANDS)
@@ -189,6 +190,7 @@ void mrc_destroy(mrc_handle* h) {
     }
     for (auto& lane : h->lanes) lane.release();
     h->wsPipe.release();
+    h->packWs.release();
     h->ws.release();
     for (DevBuf* b : {&h->inL, &h->inR, &h->inAux, &h->inAux2, &h->inAux3,
                       &h->outA, &h->outB, &h->outC, &h->outD, &h->outE, &h->outF, &h->outG})
@@ -324,6 +326,57 @@ int mrc_dev_huffman_gain(mrc_handle* h, int a, int b, int64_t n_frames, int n_st
     if (rc) return rc;
     MRC_HIP(h, launch_huffman_gain(hs->dev, n_frames, n_streams, bit_alloc, mantissa, reservoir_out, huff_table,
                                    bits_saved, reservoir_next, pick_stream(h, stream)));
+    return MRC_OK;
+}
+
+// `.pac` chunks on the device (csrc/mrc_kernels_pack.hip)
+int mrc_dev_pack_blocks(mrc_handle* h, int a, int b, int64_t n_blocks, int n_channels, int joint, int use_huffman,
+                        const int32_t* huff_table_in, const int32_t* overall_scale, const int32_t* ms_switch,
+                        const int32_t* scale_factor, const int32_t* bit_alloc, const void* mantissa, int mantissa_format,
+                        uint8_t* out, int64_t out_cap, int64_t* block_offset, int32_t* huff_table, int32_t* bits_saved,
+                        int64_t* total_bytes, void* stream) {
+    if (!h || n_blocks < 0 || n_channels < 1 || (joint && (n_channels != 2 || !ms_switch)) || !overall_scale ||
+        !scale_factor || !bit_alloc || !mantissa || !out || !block_offset || out_cap < 0 ||
+        (mantissa_format != MRC_MANTISSA_I32 && mantissa_format != MRC_MANTISSA_I16))
+        return fail(h, MRC_ERR_INVALID, "mrc_dev_pack_blocks: bad argument");
+    const HostShape* hs;
+    int rc = get_shape(h, a, b, &hs);
+    if (rc) return rc;
+    const DevShape& S = hs->dev;
+    const mrc_config& cfg = h->cfg;
+    if (cfg.n_scale_bits < 1 || cfg.n_scale_bits > 4 || cfg.n_mant_size_bits < 1 || cfg.n_mant_size_bits > 8 ||
+        cfg.blksw_bits_a < 0 || cfg.blksw_bits_a > 8 || cfg.blksw_bits_b < 0 || cfg.blksw_bits_b > 8)
+        return fail(h, MRC_ERR_INVALID, "mrc_dev_pack_blocks: field widths out of range");
+    hipStream_t st = pick_stream(h, stream);
+    const int64_t nChunks = n_blocks * n_channels;
+    if (n_blocks == 0) {
+        MRC_HIP(h, hipMemsetAsync(block_offset, 0, sizeof(int64_t), st));
+        if (total_bytes) { MRC_HIP(h, hipStreamSynchronize(st)); *total_bytes = 0; }
+        return MRC_OK;
+    }
+    static const PackTables tables = [] { PackTables t; pack_tables(&t); return t; }();
+    PackParams P;
+    P.nch = n_channels; P.joint = joint ? 1 : 0; P.useHuffman = use_huffman ? 1 : 0;
+    P.nScaleBits = cfg.n_scale_bits; P.nMantSizeBits = cfg.n_mant_size_bits;
+    P.blkBitsA = cfg.blksw_bits_a; P.blkBitsB = cfg.blksw_bits_b;
+    P.bitA = (unsigned)(1 - a / cfg.n_mdct_lines); P.bitB = (unsigned)(1 - b / cfg.n_mdct_lines);   // py2 int division
+    const size_t wsBytes = pack_workspace_bytes(nChunks);
+    MRC_HIP(h, h->packWs.reserve(wsBytes + (huff_table ? 0 : (size_t)nChunks * sizeof(int32_t))));
+    int32_t* tableOut = huff_table ? huff_table : reinterpret_cast<int32_t*>(static_cast<char*>(h->packWs.p) + wsBytes);
+    const int bound = (int)(mrc_pack_bound(&cfg, a, b, 1, joint) - 4);
+    MRC_HIP(h, launch_pack(S, P, tables, n_blocks, overall_scale, ms_switch, scale_factor, bit_alloc, mantissa,
+                           mantissa_format, huff_table_in, tableOut, bits_saved, out, (long long)out_cap,
+                           reinterpret_cast<long long*>(block_offset), h->packWs.p, bound, st));
+    if (total_bytes) {                                 // the caller wants the size now: one synchronisation
+        long long total = 0;
+        int bad = 0;
+        MRC_HIP(h, hipMemcpyAsync(&total, pack_total_bytes(h->packWs.p, nChunks), sizeof(total), hipMemcpyDeviceToHost, st));
+        MRC_HIP(h, hipMemcpyAsync(&bad, pack_error_flag(h->packWs.p, nChunks), sizeof(bad), hipMemcpyDeviceToHost, st));
+        MRC_HIP(h, hipStreamSynchronize(st));
+        *total_bytes = total;
+        if (bad) return fail(h, MRC_ERR_INVALID, "mrc_dev_pack_blocks: huff_table_in holds an id that is neither 0..3 nor 15");
+        if (total > out_cap) return fail(h, MRC_ERR_NOMEM, "mrc_dev_pack_blocks: out_cap too small (see total_bytes)");
+    }
     return MRC_OK;
 }
 

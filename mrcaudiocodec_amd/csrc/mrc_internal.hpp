@@ -102,6 +102,28 @@ hipError_t launch_decode(const DevShape& S, int64_t nBlocks, int nStreams, const
                          const int* scaleFactor, const int* bitAlloc, const int* mantissa, const int64_t* outOffset,
                          double* outL, double* outR, hipStream_t st);
 hipError_t launch_pcm16(int64_t n, const double* x, short* out, hipStream_t st);
+// mrc_kernels_pack.hip -- `.pac` chunk packing on the device
+constexpr int kPackLutSize = 65;     // the largest value in any Huffman table is 64
+constexpr int kPackRawTable = 15;    // codecThem.py:149
+struct PackTables {                  // mrc_pack.cpp: pack_tables()
+    // per table and value (last index: any other value): code | length << 16 | 1 << 31 where the raw mantissa follows
+    unsigned emit[4 * (kPackLutSize + 1)];
+    int escape[4];
+};
+struct PackParams {
+    int nch, joint, useHuffman;
+    int nScaleBits, nMantSizeBits, blkBitsA, blkBitsB;      // field widths
+    unsigned bitA, bitB;                                    // block-switching bits of this shape (pacfileThem.py:720-723)
+};
+void pack_tables(PackTables* out);                          // host, from the table data in mrc_pack.cpp
+size_t pack_workspace_bytes(int64_t nChunks);
+hipError_t launch_pack(const DevShape& S, const PackParams& P, const PackTables& T, int64_t nBlocks, const int* oscale,
+                       const int* msSwitch, const int* scaleFactor, const int* bitAlloc, const void* mant, int mantFmt,
+                       const int* tableIn /* nullable */, int* tableOut, int* bitsSaved /* nullable */, unsigned char* out,
+                       long long outCap, long long* blockOffset /* [nBlocks + 1] */, void* ws /* pack_workspace_bytes */,
+                       int boundBytes /* largest chunk payload */, hipStream_t st);
+const int* pack_error_flag(const void* ws, int64_t nChunks);          // device addresses inside ws
+const long long* pack_total_bytes(const void* ws, int64_t nChunks);
 // mrc_kernels_huff.hip
 hipError_t launch_huffman_gain(const DevShape& S, int64_t nFrames, int nStreams, const int* bitAlloc,
                                const int* mantissa, const int* reservoirOut, int* huffTable, int* bitsSaved,

@@ -1,0 +1,328 @@
+// `.pac` chunk packing ON THE DEVICE: the bytes WriteDataBlock / JointWriteDataBlock append per block
+// (pacfileThem.py:652-781, 825-963; bit order of bitpack.py:36-101; Huffman choice and recoding of
+// codecThem.py:136-203), produced from the encoder's outputs where they lie in HBM -- so that a WAV -> .pac
+// pipeline copies ~350 bytes per block back to the host instead of the 2 KB mantissa plane, and no host thread
+// touches a bit.  Same byte image as the host packer (csrc/mrc_pack.cpp), which the tests compare it with.
+//
+// Three steps, all wave-granular (one 64-lane wavefront per channel chunk, no workgroup barrier after the
+// table staging):
+//   pack_plan_kernel    per chunk: price the four Huffman tables and raw in ONE pass over the mantissas (or take
+//                       the table from huffman_gain_kernel / the caller), count the bits the writer will emit
+//                       -> table id, bits_saved, chunk size in bytes (pacfileThem.py:706-707);
+//   pack_scan_*         exclusive prefix sum of (4 + chunk bytes) -> where every chunk starts, block offsets;
+//   pack_write_kernel   per chunk: per-line code lengths -> prefix sum over the lines in LDS -> every lane ORs
+//                       its codes into a zeroed big-endian word image of the chunk in LDS (ds_or_b32; a code of
+//                       at most 25 bits touches at most two words) -> band headers at the positions the prefix
+//                       sum gives -> the image goes out as bytes behind the 4-byte little-endian length.
+// Line k's first bit sits at  header bits + (band(k) + 1) (nMantSizeBits + nScaleBits) + sum of the code
+// lengths of the lines before it: the band headers are a closed-form term, so ONE prefix sum serves lines and
+// headers alike.
+#include "mrc_device.hpp"
+
+namespace mrc {
+using namespace dev;
+namespace {
+
+constexpr int kWavesPerGroup = 4;
+constexpr int kScanTile = 1024;                      // chunks per workgroup of the position scan
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);      // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);      // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);     // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, false);     // row_ror:8
+    const uint2v r16 = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = (int)(r16.x + r16.y);
+    const uint2v r32 = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)(r32.x + r32.y);
+}
+// inclusive prefix sum over the 64 lanes (Kogge-Stone in 16-lane rows by DPP shifts, row totals by row_bcast)
+__device__ __forceinline__ int wave_scan_i(int v) {
+    v += __builtin_amdgcn_mov_dpp(v, 0x111, 0xf, 0xf, true);            // row_shr:1 (bound_ctrl: 0 shifted in)
+    v += __builtin_amdgcn_mov_dpp(v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_mov_dpp(v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_mov_dpp(v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+// LDS traffic between the lanes of ONE wave: order this wave's DS operations (no other wave is involved)
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__device__ __forceinline__ unsigned lut_index(int v) { return (unsigned)v < (unsigned)kPackLutSize ? (unsigned)v : (unsigned)kPackLutSize; }
+
+// what the writer emits for one mantissa under `table` (pacfileThem.py:685-703, 742-760): -> (bits, length)
+__device__ __forceinline__ void code_of(const unsigned* __restrict__ emit, int table, int v, int ba, unsigned* bits, int* len) {
+    if (table == kPackRawTable) { *bits = (unsigned)v & ((1u << ba) - 1u); *len = ba; return; }
+    const unsigned e = emit[table * (kPackLutSize + 1) + lut_index(v)];
+    const int n = (int)((e >> 16) & 0x7fffu);
+    if (e >> 31) { *bits = ((e & 0xffffu) << ba) | ((unsigned)v & ((1u << ba) - 1u)); *len = n + ba; }   // escape code + raw mantissa
+    else { *bits = e & 0xffffu; *len = n; }
+}
+
+template <class MantT>
+__global__ __launch_bounds__(kWave * kWavesPerGroup) void pack_plan_kernel(
+    DevShape S, PackParams P, PackTables T, int64_t nChunks, const int* __restrict__ bitAlloc,
+    const MantT* __restrict__ mant, const int* __restrict__ tableIn, int* __restrict__ tableOut,
+    int* __restrict__ bitsSaved, int* __restrict__ chunkBytes, int* __restrict__ errorFlag) {
+    __shared__ unsigned sEmit[4 * (kPackLutSize + 1)];
+    for (int i = threadIdx.x; i < 4 * (kPackLutSize + 1); i += blockDim.x) sEmit[i] = T.emit[i];
+    __syncthreads();
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int64_t c = (int64_t)blockIdx.x * kWavesPerGroup + wave;
+    if (c >= nChunks) return;
+    const int M = S.halfN, nb = S.nBands;
+    const int* ba = bitAlloc + c * nb;
+    const MantT* m = mant + c * (int64_t)M;
+    // ONE pass: the raw size, the PRICE of each table (codecThem.py:161-180: a value without a code costs the escape
+    // code + the raw mantissa, the escape VALUE itself its code alone) and what the WRITER emits for it (194-200: the
+    // escape value is followed by its raw mantissa too)
+    int raw = 0, cost[4] = {0, 0, 0, 0}, wr[4] = {0, 0, 0, 0};
+    for (int k = lane; k < M; k += kWave) {
+        const int b = ba[S.bandOfLine[k]];
+        if (b) {
+            const unsigned idx = lut_index((int)m[k]);
+            raw += b;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const unsigned e = sEmit[t * (kPackLutSize + 1) + idx];
+                const int n = (int)((e >> 16) & 0x7fffu);
+                const bool follows = (e >> 31) != 0;
+                wr[t] += n + (follows ? b : 0);
+                cost[t] += n + ((follows && (int)idx != T.escape[t]) ? b : 0);
+            }
+        }
+    }
+    raw = wave_sum_i(raw);
+    int best = raw, table = kPackRawTable, mantBits = raw, saved = 0;
+    int wsum[4], csum[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { csum[t] = wave_sum_i(cost[t]); wsum[t] = wave_sum_i(wr[t]); }
+    if (tableIn) {                                                   // chosen elsewhere (huffman_gain_kernel / the caller)
+        table = tableIn[c];
+        if (table != kPackRawTable && (table < 0 || table > 3)) { table = kPackRawTable; if (lane == 0) atomicOr(errorFlag, 1); }
+    } else if (P.useHuffman) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (csum[t] < best) { best = csum[t]; table = t; }         // strictly less: raw, then the first table, win ties
+        saved = raw - best;                                          // codecThem.py:202
+    }
+    if (table != kPackRawTable) mantBits = table == 0 ? wsum[0] : table == 1 ? wsum[1] : table == 2 ? wsum[2] : wsum[3];
+    const int ch = (int)(c % P.nch);
+    int bits = 4 + P.blkBitsA + P.blkBitsB + nb * (P.nMantSizeBits + P.nScaleBits) + mantBits;
+    if (P.joint) { if (ch == 0) bits += nb + 4 * P.nScaleBits; }      // pacfileThem.py:826-833
+    else bits += P.nScaleBits;                                       // pacfileThem.py:655
+    if (lane == 0) {
+        chunkBytes[c] = (bits + 7) / 8;                              // pacfileThem.py:706-707
+        tableOut[c] = table;
+        if (bitsSaved) bitsSaved[c] = saved;
+    }
+}
+
+// ---- positions: pos[c] = sum over c' < c of (4 + chunkBytes[c']) ------------------------------------------------
+__global__ __launch_bounds__(256) void pack_scan_sums_kernel(int64_t n, const int* __restrict__ chunkBytes,
+                                                              long long* __restrict__ tileSum) {
+    __shared__ int sWave[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + 4 * threadIdx.x;
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (base + j < n) s += 4 + chunkBytes[base + j];
+    s = wave_sum_i(s);
+    if ((threadIdx.x & 63) == 0) sWave[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) tileSum[blockIdx.x] = (long long)sWave[0] + sWave[1] + sWave[2] + sWave[3];
+}
+__global__ void pack_scan_tiles_kernel(int nTiles, long long* __restrict__ tileSum, long long* __restrict__ total) {
+    if (threadIdx.x || blockIdx.x) return;                           // a few thousand tiles at most: one lane walks them
+    long long run = 0;
+    for (int g = 0; g < nTiles; ++g) { const long long t = tileSum[g]; tileSum[g] = run; run += t; }
+    *total = run;
+}
+__global__ __launch_bounds__(256) void pack_scan_apply_kernel(int64_t n, int nch, const int* __restrict__ chunkBytes,
+                                                               const long long* __restrict__ tileSum,
+                                                               const long long* __restrict__ total,
+                                                               long long* __restrict__ pos, long long* __restrict__ blockOffset) {
+    __shared__ int sWave[4];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + 4 * threadIdx.x;
+    int v[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = base + j < n ? 4 + chunkBytes[base + j] : 0; s += v[j]; }
+    const int incl = wave_scan_i(s);
+    if ((threadIdx.x & 63) == 63) sWave[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    long long run = tileSum[blockIdx.x] + (incl - s);
+    for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) run += sWave[w];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int64_t c = base + j;
+        if (c < n) {
+            pos[c] = run;
+            if (c % nch == 0) blockOffset[c / nch] = run;
+        }
+        run += v[j];
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) blockOffset[n / nch] = *total;
+}
+
+// ---- payloads ---------------------------------------------------------------------------------------------------
+// OR the lowest `len` (1..25) bits of `val` into the MSB-first bit stream held as big-endian 32-bit words
+__device__ __forceinline__ void put_bits(unsigned* __restrict__ w, int off, unsigned val, int len) {
+    const int wi = off >> 5, sh = 32 - (off & 31) - len;
+    if (sh >= 0) atomicOr(&w[wi], val << sh);
+    else { atomicOr(&w[wi], val >> (-sh)); atomicOr(&w[wi + 1], val << (32 + sh)); }
+}
+__device__ __forceinline__ int pad16(int k) { return k + (k >> 4); }     // (a lane's run of 16 entries starts on its own bank)
+
+template <class MantT>
+__global__ __launch_bounds__(kWave * kWavesPerGroup) void pack_write_kernel(
+    DevShape S, PackParams P, PackTables T, int64_t nChunks, const int* __restrict__ oscale,
+    const int* __restrict__ msSwitch, const int* __restrict__ scaleFactor, const int* __restrict__ bitAlloc,
+    const MantT* __restrict__ mant, const int* __restrict__ table, const int* __restrict__ chunkBytes,
+    const long long* __restrict__ pos, unsigned char* __restrict__ out, long long outCap, int wordsPerWave) {
+    extern __shared__ unsigned smem[];
+    unsigned* sEmit = smem;                                                     // [4 (kPackLutSize + 1)]
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
+    const int M = S.halfN, nb = S.nBands;
+    const int prefLen = pad16(M) + 2;
+    unsigned* w = smem + 4 * (kPackLutSize + 1) + wave * (wordsPerWave + prefLen + kWave);   // the chunk's image
+    int* pref = reinterpret_cast<int*>(w + wordsPerWave);                       // [pad16(M) + 1] code lengths -> prefix sums
+    int* laneBase = pref + prefLen;                                             // [64]
+    for (int i = threadIdx.x; i < 4 * (kPackLutSize + 1); i += blockDim.x) sEmit[i] = T.emit[i];
+    for (int i = lane; i < wordsPerWave; i += kWave) w[i] = 0u;
+    __syncthreads();
+    const int64_t c = (int64_t)blockIdx.x * kWavesPerGroup + wave;
+    if (c >= nChunks) return;
+    const int64_t blk = c / P.nch;
+    const int ch = (int)(c % P.nch);
+    const int nBytes = chunkBytes[c];
+    const long long p0 = pos[c];
+    if (p0 + 4 + nBytes > outCap || nBytes > 4 * (wordsPerWave - 1)) return;    // (the caller reports the overflow)
+    const int tbl = table[c];
+    const int* ba = bitAlloc + c * nb;
+    const int* sf = scaleFactor + c * nb;
+    const MantT* m = mant + c * (int64_t)M;
+    const int hb = P.nMantSizeBits + P.nScaleBits;
+    // chunk header: table id, block-switching bits, overall scale(s), M/S switch bits (pacfileThem.py:716-728, 892-910)
+    int hdr = 4 + P.blkBitsA + P.blkBitsB;
+    if (lane == 0) {
+        put_bits(w, 0, (unsigned)tbl & 15u, 4);
+        if (P.blkBitsA) put_bits(w, 4, P.bitA & ((1u << P.blkBitsA) - 1u), P.blkBitsA);
+        if (P.blkBitsB) put_bits(w, 4 + P.blkBitsA, P.bitB & ((1u << P.blkBitsB) - 1u), P.blkBitsB);
+    }
+    const unsigned scaleMask = (1u << P.nScaleBits) - 1u;
+    if (P.joint) {
+        if (ch == 0) {
+            if (lane < 4) put_bits(w, hdr + lane * P.nScaleBits, (unsigned)oscale[blk * 4 + lane] & scaleMask, P.nScaleBits);   // L, R, M, S
+            if (lane < nb) put_bits(w, hdr + 4 * P.nScaleBits + lane, (unsigned)msSwitch[blk * nb + lane] & 1u, 1);
+            hdr += 4 * P.nScaleBits + nb;
+        }
+    } else {
+        if (lane == 0) put_bits(w, hdr, (unsigned)oscale[blk * P.nch + ch] & scaleMask, P.nScaleBits);
+        hdr += P.nScaleBits;
+    }
+    // code length of every line -> LDS (coalesced over the lines), then an exclusive prefix sum: lane l scans the run
+    // [l LPL, (l + 1) LPL) in place, the lane totals are scanned in registers
+    for (int k = lane; k < M; k += kWave) {
+        const int b = ba[S.bandOfLine[k]];
+        int len = 0;
+        if (b) { unsigned bits; code_of(sEmit, tbl, (int)m[k], b, &bits, &len); }
+        pref[pad16(k)] = len;
+    }
+    wave_sync();
+    const int lpl = (M + kWave - 1) / kWave;
+    {
+        int run = 0;
+        const int k0 = lane * lpl, k1 = min(k0 + lpl, M);
+        for (int k = k0; k < k1; ++k) { const int t = pref[pad16(k)]; pref[pad16(k)] = run; run += t; }
+        const int incl = wave_scan_i(run);
+        laneBase[lane] = incl - run;
+        if (lane == kWave - 1) pref[pad16(M) + 1] = incl;            // the total: the prefix of a band that starts at M
+    }
+    wave_sync();
+    auto prefix_at = [&](int k) { return k < M ? pref[pad16(k)] + laneBase[k / lpl] : pref[pad16(M) + 1]; };
+    // mantissas
+    for (int k = lane; k < M; k += kWave) {
+        const int band = S.bandOfLine[k];
+        const int b = ba[band];
+        if (b) {
+            unsigned bits; int len;
+            code_of(sEmit, tbl, (int)m[k], b, &bits, &len);
+            if (len) put_bits(w, hdr + (band + 1) * hb + prefix_at(k), bits, len);
+        }
+    }
+    // band headers: bit allocation (stored one lower) and scale factor (pacfileThem.py:730-732)
+    if (lane < nb) {
+        const int b = ba[lane];
+        const unsigned v = ((unsigned)(b ? b - 1 : 0) << P.nScaleBits) | ((unsigned)sf[lane] & scaleMask);
+        put_bits(w, hdr + lane * hb + prefix_at(S.bandLo[lane]), v & ((1u << hb) - 1u), hb);
+    }
+    wave_sync();
+    // out: 4-byte little-endian length, then the image MSB first
+    unsigned char* dst = out + p0;
+    if (lane < 4) dst[lane] = (unsigned char)(((unsigned)nBytes >> (8 * lane)) & 255u);
+    for (int j = lane; j < nBytes; j += kWave) dst[4 + j] = (unsigned char)((w[j >> 2] >> (24 - 8 * (j & 3))) & 255u);
+}
+
+}  // namespace
+
+size_t pack_workspace_bytes(int64_t nChunks) {
+    const int64_t nTiles = (nChunks + kScanTile - 1) / kScanTile;
+    return (size_t)nChunks * (sizeof(int) + sizeof(long long)) + (size_t)(nTiles + 2) * sizeof(long long) + 64;
+}
+
+template <class MantT>
+static hipError_t launch_pack_t(const DevShape& S, const PackParams& P, const PackTables& T, int64_t nBlocks,
+                                const int* oscale, const int* msSwitch, const int* scaleFactor, const int* bitAlloc,
+                                const MantT* mant, const int* tableIn, int* tableOut, int* bitsSaved, unsigned char* out,
+                                long long outCap, long long* blockOffset, void* ws, int boundBytes, hipStream_t st) {
+    const int64_t nChunks = nBlocks * P.nch;
+    const int64_t nTiles = (nChunks + kScanTile - 1) / kScanTile;
+    // workspace: pos [nChunks] | tile sums [nTiles] | total | error flag | chunkBytes [nChunks]
+    long long* pos = reinterpret_cast<long long*>(ws);
+    long long* tileSum = pos + nChunks;
+    long long* total = tileSum + nTiles;
+    int* errorFlag = reinterpret_cast<int*>(total + 1);
+    int* chunkBytes = errorFlag + 2;
+    (void)hipMemsetAsync(errorFlag, 0, sizeof(int), st);
+    const unsigned groups = (unsigned)((nChunks + kWavesPerGroup - 1) / kWavesPerGroup);
+    hipLaunchKernelGGL((pack_plan_kernel<MantT>), dim3(groups), dim3(kWave * kWavesPerGroup), 0, st, S, P, T, nChunks,
+                       bitAlloc, mant, tableIn, tableOut, bitsSaved, chunkBytes, errorFlag);
+    hipLaunchKernelGGL(pack_scan_sums_kernel, dim3((unsigned)nTiles), dim3(256), 0, st, nChunks, chunkBytes, tileSum);
+    hipLaunchKernelGGL(pack_scan_tiles_kernel, dim3(1), dim3(64), 0, st, (int)nTiles, tileSum, total);
+    hipLaunchKernelGGL(pack_scan_apply_kernel, dim3((unsigned)nTiles), dim3(256), 0, st, nChunks, P.nch, chunkBytes,
+                       tileSum, total, pos, blockOffset);
+    const int wordsPerWave = (boundBytes + 3) / 4 + 2;
+    const int prefLen = (S.halfN + (S.halfN >> 4)) + 2;
+    const size_t lds = sizeof(unsigned) * (4 * (kPackLutSize + 1) + (size_t)kWavesPerGroup * (wordsPerWave + prefLen + kWave));
+    hipLaunchKernelGGL((pack_write_kernel<MantT>), dim3(groups), dim3(kWave * kWavesPerGroup), lds, st, S, P, T, nChunks,
+                       oscale, msSwitch, scaleFactor, bitAlloc, mant, tableOut, chunkBytes, pos, out, outCap, wordsPerWave);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack(const DevShape& S, const PackParams& P, const PackTables& T, int64_t nBlocks, const int* oscale,
+                       const int* msSwitch, const int* scaleFactor, const int* bitAlloc, const void* mant, int mantFmt,
+                       const int* tableIn, int* tableOut, int* bitsSaved, unsigned char* out, long long outCap,
+                       long long* blockOffset, void* ws, int boundBytes, hipStream_t st) {
+    if (nBlocks <= 0) return hipSuccess;
+    if (mantFmt == MRC_MANTISSA_I16)
+        return launch_pack_t(S, P, T, nBlocks, oscale, msSwitch, scaleFactor, bitAlloc, (const unsigned short*)mant, tableIn,
+                             tableOut, bitsSaved, out, outCap, blockOffset, ws, boundBytes, st);
+    return launch_pack_t(S, P, T, nBlocks, oscale, msSwitch, scaleFactor, bitAlloc, (const int*)mant, tableIn, tableOut,
+                         bitsSaved, out, outCap, blockOffset, ws, boundBytes, st);
+}
+
+const int* pack_error_flag(const void* ws, int64_t nChunks) {
+    const int64_t nTiles = (nChunks + kScanTile - 1) / kScanTile;
+    return reinterpret_cast<const int*>(reinterpret_cast<const long long*>(ws) + nChunks + nTiles + 1);
+}
+const long long* pack_total_bytes(const void* ws, int64_t nChunks) {
+    const int64_t nTiles = (nChunks + kScanTile - 1) / kScanTile;
+    return reinterpret_cast<const long long*>(ws) + nChunks + nTiles;
+}
+
+}  // namespace mrc

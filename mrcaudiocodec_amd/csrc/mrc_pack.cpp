@@ -318,6 +318,16 @@ inline uint32_t get_u16le(const uint8_t* p) { return p[0] | (p[1] << 8); }
 
 }  // namespace
 
+namespace mrc {
+void pack_tables(PackTables* out) {
+    static_assert(kPackLutSize == kLutSize && kPackRawTable == kRawTable, "device and host packer tables");
+    for (int t = 0; t < 4; ++t) {
+        for (int v = 0; v <= kLutSize; ++v) out->emit[t * (kLutSize + 1) + v] = kLut.emit[t][v];
+        out->escape[t] = kTables[t].escape;
+    }
+}
+}  // namespace mrc
+
 extern "C" {
 
 int mrc_band_table(const mrc_config* cfg, int a, int b, int32_t* n_bands, int32_t* n_lines) {
