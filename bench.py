@@ -450,6 +450,22 @@ def main():
                             "each way with both directions busy at 16 / 64 MiB per copy",
             "equals_resident_result": same}
         del dev_out
+        # ... and with the back end on the device as well: the same PCM -> `.pac` chunk bytes in page-locked host memory
+        pac_buf = pin((Fh * HOP + 4096,), np.uint8)
+        pac_chunk = best
+        enc.h.encode_stream_pcm16_pac(host_pcm, None, None, True, pac_chunk, {"bytes": pac_buf})
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            pac = enc.h.encode_stream_pcm16_pac(host_pcm, None, None, True, pac_chunk, {"bytes": pac_buf})
+            ts.append(time.perf_counter() - t0)
+        tp = float(np.median(ts))
+        line["host_to_host"]["pac"] = {
+            "value": round(Fh * HOP / tp / 1e6, 3), "unit": "Msamples/s", "chunk_frames": pac_chunk,
+            "bytes_per_frame": round(pac["bytes"].size / Fh, 1),
+            "what": "the same PCM -> .pac chunk bytes (Huffman pricing + bit packing on the device, mrc_encode_stream_pcm16_pac) "
+                    "in page-locked host memory"}
+        del pac
         for p in keep:
             p.free()
 
@@ -470,6 +486,7 @@ def main():
             "roofline": roofline_of(rows_j, {"traffic_source": tj_src}), "kernels": rows_j}}
         # host back end on these outputs (reported separately)
         cfgs["stereo_ms"]["host_pack"] = host_pack_rate(np, ppac, out, min(Fs, 16384))
+        cfgs["stereo_ms"]["device_pack"] = device_pack_rate(torch, enc, out, Fs, args.steps)
         del sl, sr, out
 
         # ---- configs[3]: block switching (long / start / 8 short / stop), mono, resident
@@ -536,6 +553,26 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def device_pack_rate(torch, enc, out, n, steps):
+    """The same back end ON THE DEVICE (mrc_dev_pack_blocks: Huffman pricing, chunk sizes, bit packing of the outputs
+    where the encoder left them), reported beside the host packer; not part of `value`."""
+    L = enc.h.cfg.n_mdct_lines
+    res = {}
+    for name, use in (("huffman_priced_on_device", True), ("raw", False)):
+        packed = enc.pack(L, L, out, use_huffman=use)               # warm-up, buffer sizing
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            packed = enc.pack(L, L, out, use_huffman=use)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        res[name + "_Msamples_s"] = round(2.0 * n * L / dt / 1e6, 1)
+        res[name + "_bytes_per_frame"] = round(packed["bytes"].numel() / n, 1)
+    res["note"] = ("joint chunks of %d stereo frames, resident in HBM -> .pac bytes in HBM; one synchronisation per call "
+                   "(the byte count)" % n)
+    return res
 
 
 def host_pack_rate(np, ppac, out, n, threads=None):

@@ -120,7 +120,7 @@ int mrc_encode_joint_blocks(mrc_handle* h, int64_t n_blocks, const double* left,
  * Frames are independent given reservoir_in [n] (NULL = zeros).  Outputs as mrc_encode_mono / _joint for a = b = L,
  * except the mantissa plane, which is uint16 [n][streams][L] (codes are at most 16 bits wide, codecThem.py:292-293).
  * The work is cut into chunks of chunk_frames frames (0: 32 768, fewer for streams shorter than six chunks) over a
- * ring of three chunk buffers; ALL uploads are queued on one HIP stream, all kernels on the handle's stream, all
+ * ring of four chunk buffers; ALL uploads are queued on one HIP stream, all kernels on the handle's stream, all
  * downloads on a third, ordered by events, so chunk i+1 is copied in and chunk i-1 copied out beside chunk i's
  * kernels (one stream per direction: what the copy engines of the MI355X box run fastest).  With host buffers from
  * mrc_host_alloc / mrc_host_register (page-locked) the copies are truly asynchronous; pageable buffers work, slower.
@@ -129,6 +129,19 @@ int mrc_encode_stream_pcm16(mrc_handle* h, int64_t n_frames, const int16_t* pcm_
                             const int32_t* reservoir_in, int32_t* overall_scale, int32_t* ms_switch,
                             int32_t* scale_factor, int32_t* bit_alloc, uint16_t* mantissa16, int32_t* reservoir_out,
                             int64_t chunk_frames);
+/* The same pipeline with the back end on the device too (mrc_dev_pack_blocks behind the kernels of every chunk):
+ * 16-bit PCM in host memory -> the `.pac` CHUNK BYTES of the frames in host memory, what WriteDataBlock (mono:
+ * one chunk per frame) / JointWriteDataBlock (stereo: two) would append frame after frame (pacfileThem.py:652-781,
+ * 825-963) -- a WAV -> .pac pipeline is then: this call, file header (mrc_pac_header), write.  Only ~350 bytes per
+ * frame and channel come back over PCIe instead of the 2 KB mantissa plane.  Frames independent given
+ * reservoir_in [n] (NULL = zeros); use_huffman: price the four tables per chunk (codecThem.py:136-203), else raw.
+ * out [out_cap] (size it with n * channels * mrc_pack_bound(cfg, L, L, 1, joint), or less and retry on
+ * MRC_ERR_NOMEM), block_offset [n + 1] byte offset of every frame's chunks, total_bytes: the sum; huff_table /
+ * bits_saved [n][channels] and reservoir_out [n] may be NULL.  All pointers HOST memory, page-locked for speed. */
+int mrc_encode_stream_pcm16_pac(mrc_handle* h, int64_t n_frames, const int16_t* pcm_left, const int16_t* pcm_right,
+                                const int32_t* reservoir_in, int use_huffman, uint8_t* out, int64_t out_cap,
+                                int64_t* block_offset, int32_t* huff_table, int32_t* bits_saved, int32_t* reservoir_out,
+                                int64_t* total_bytes, int64_t chunk_frames);
 /* Page-locked host memory (hipHostMalloc / hipHostRegister): no handle needed, any thread. */
 int mrc_host_alloc(void** out, size_t bytes);
 int mrc_host_free(void* p);

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MRC_HIP_LIBRARY") or os.path.join(_HERE, "libmrc_hip.so")   # override: profiling builds
 
 MRC_MAX_BANDS = 32
+MRC_ERR_NOMEM = -4
 _i32p = C.POINTER(C.c_int32)
 _i64p = C.POINTER(C.c_int64)
 _f64p = C.POINTER(C.c_double)
@@ -90,6 +91,8 @@ def _load():
                                               _i32p, _i32p]),
         "mrc_encode_stream_pcm16": (C.c_int, [H, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]),
+        "mrc_encode_stream_pcm16_pac": (C.c_int, [H, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, _i64p, C.c_int64]),
         "mrc_host_alloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
         "mrc_host_free": (C.c_int, [C.c_void_p]),
         "mrc_host_register": (C.c_int, [C.c_void_p, C.c_size_t]),
@@ -326,6 +329,48 @@ class Handle:
                                                 vp(res.get("ms_switch")), vp(res["scale_factor"]), vp(res["bit_alloc"]),
                                                 vp(res["mantissa"]), vp(res["reservoir_out"]), int(chunk_frames)))
         return res
+
+    def encode_stream_pcm16_pac(self, pcm_left, pcm_right=None, reservoir_in=None, use_huffman=True, chunk_frames=0,
+                                out=None, bytes_per_chunk=None):
+        """mrc_encode_stream_pcm16_pac: int16 PCM stream(s) [(n+1) * L] in host memory -> the `.pac` chunk bytes of the n
+        long blocks in host memory (encode kernels + Huffman pricing + bit packing on the device, pipelined).  `out` may hold
+        a preallocated (ideally page-locked) uint8 array `bytes`; too small a buffer is retried once at the worst-case size.
+        -> dict: bytes (the used prefix), block_offset [n + 1], huff_table / bits_saved [n][channels], reservoir_out [n]."""
+        L = self.cfg.n_mdct_lines
+        pl = np.ascontiguousarray(pcm_left, dtype=np.int16)
+        n = pl.size // L - 1
+        if pl.ndim != 1 or pl.size != (n + 1) * L or n < 0:
+            raise ValueError("pcm_left must be int16 [(n_frames + 1) * %d]" % L)
+        joint = pcm_right is not None
+        pr = None
+        if joint:
+            pr = np.ascontiguousarray(pcm_right, dtype=np.int16)
+            if pr.shape != pl.shape:
+                raise ValueError("pcm_right must match pcm_left")
+        nch = 2 if joint else 1
+        bound = int(lib.mrc_pack_bound(C.byref(self.cfg), L, L, 1, 1 if joint else 0))
+        buf = None if out is None else out.get("bytes")
+        if buf is not None and (buf.dtype != np.uint8 or buf.ndim != 1 or not buf.flags.c_contiguous):
+            raise ValueError("out['bytes'] must be a C-contiguous 1-D uint8 array")
+        if buf is None:
+            buf = np.empty(max(1, n * nch * int(bytes_per_chunk or L) + 4096), np.uint8)
+        offs = np.zeros(n + 1, np.int64)
+        table, saved = np.zeros((n, nch), np.int32), np.zeros((n, nch), np.int32)
+        res_out = np.zeros(n, np.int32)
+        res_in = _reservoir(reservoir_in, n)
+        total = np.zeros(1, np.int64)
+        vp = lambda arr: None if arr is None else arr.ctypes.data_as(C.c_void_p)
+        for attempt in (0, 1):
+            rc = lib.mrc_encode_stream_pcm16_pac(self._h, n, vp(pl), vp(pr), vp(res_in), 1 if use_huffman else 0, vp(buf),
+                                                 buf.size, vp(offs), vp(table), vp(saved), vp(res_out),
+                                                 total.ctypes.data_as(_i64p), int(chunk_frames))
+            if rc == MRC_ERR_NOMEM and attempt == 0 and buf.size < n * nch * bound:
+                buf = np.empty(n * nch * bound, np.uint8)
+                continue
+            self._check(rc)
+            break
+        return {"bytes": buf[:int(total[0])], "block_offset": offs, "huff_table": table, "bits_saved": saved,
+                "reservoir_out": res_out}
 
     def pcm_to_float(self, pcm):
         pcm = np.ascontiguousarray(pcm, dtype=np.int16)

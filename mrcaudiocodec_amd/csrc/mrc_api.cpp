@@ -46,16 +46,21 @@ struct Workspace {
 // copy both ways (tools/pcie_rates.py), which is what one-stream-per-chunk pipelining amounts to.
 struct Lane {
     DevBuf pcmL, pcmR, resIn, oScale, ms, ba, sf, mant, resOut;
+    DevBuf pacBytes, pacOffs, pacTable, pacSaved;                // mrc_encode_stream_pcm16_pac: the chunk's packed form
+    long long* pacTotal = nullptr;                               // page-locked: the chunk's byte count, read by the host
     hipEvent_t evIn = nullptr, evK = nullptr, evOut = nullptr;   // chunk copied in / encoded / copied out
     void release() {
-        for (DevBuf* b : {&pcmL, &pcmR, &resIn, &oScale, &ms, &ba, &sf, &mant, &resOut}) b->release();
+        for (DevBuf* b : {&pcmL, &pcmR, &resIn, &oScale, &ms, &ba, &sf, &mant, &resOut, &pacBytes, &pacOffs, &pacTable, &pacSaved})
+            b->release();
+        if (pacTotal) (void)hipHostFree(pacTotal);
+        pacTotal = nullptr;
         for (hipEvent_t* e : {&evIn, &evK, &evOut}) {
             if (*e) (void)hipEventDestroy(*e);
             *e = nullptr;
         }
     }
 };
-constexpr int kLanes = 3;
+constexpr int kLanes = 4;          // chunk buffers in flight (mrc_encode_stream_pcm16_pac reads sizes two chunks behind)
 constexpr int kKernelEvents = 6;     // boundaries of: mdct | smr | band_stats | bitalloc | quantize
 
 struct mrc_handle {
@@ -649,6 +654,149 @@ int mrc_encode_stream_pcm16(mrc_handle* h, int64_t n_frames, const int16_t* pcm_
     h->timing = wasTiming;
     if (rc != MRC_OK) return rc;
     for (hipStream_t st : {h->stIn, stK, h->stOut}) MRC_HIP(h, hipStreamSynchronize(st));
+    return MRC_OK;
+}
+
+// ---- 16-bit PCM in host memory -> `.pac` chunk bytes in host memory, pipelined ---------------------------------
+// mrc_encode_stream_pcm16 with the back end of mrc_dev_pack_blocks behind the kernels of every chunk: what comes back
+// over PCIe is the packed chunks (a few hundred bytes per frame and channel) instead of the mantissa plane.  The size of
+// a chunk's packed form is only known once its pack kernels have run: the host reads it (8 bytes, page-locked) one chunk
+// BEHIND the chunk it is queueing, so the wait never leaves the device idle.
+int mrc_encode_stream_pcm16_pac(mrc_handle* h, int64_t n_frames, const int16_t* pcm_left, const int16_t* pcm_right,
+                                const int32_t* reservoir_in, int use_huffman, uint8_t* out, int64_t out_cap,
+                                int64_t* block_offset, int32_t* huff_table, int32_t* bits_saved, int32_t* reservoir_out,
+                                int64_t* total_bytes, int64_t chunk_frames) {
+    if (!h || !pcm_left || !out || !block_offset || !total_bytes || n_frames < 0 || chunk_frames < 0 || out_cap < 0)
+        return fail(h, MRC_ERR_INVALID, "mrc_encode_stream_pcm16_pac: bad argument");
+    *total_bytes = 0;
+    block_offset[0] = 0;
+    if (n_frames == 0) return MRC_OK;
+    const int L = h->cfg.n_mdct_lines;
+    const HostShape* hs;
+    MRC_TRY(get_shape(h, L, L, &hs));
+    const DevShape& S = hs->dev;
+    const mrc_config& cfg = h->cfg;
+    const int joint = pcm_right ? 1 : 0, nsig = joint ? 4 : 1, nch = joint ? 2 : 1;
+    int64_t chunk = chunk_frames;
+    if (!chunk)
+        for (chunk = 32768; chunk > 8192 && n_frames < 6 * chunk;) chunk /= 2;
+    if (chunk > n_frames) chunk = n_frames;
+    const int64_t bound = mrc_pack_bound(&cfg, L, L, 1, joint);             // worst case per channel chunk, length field included
+    if (bound < 0) return fail(h, MRC_ERR_INVALID, "mrc_encode_stream_pcm16_pac: field widths out of range");
+    for (hipStream_t* st : {&h->stIn, &h->stOut})
+        if (!*st) MRC_HIP(h, hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    const hipStream_t stK = h->stream;
+    const size_t szPcm = (size_t)(chunk + 1) * L * sizeof(int16_t);
+    const size_t pacCap = (size_t)chunk * nch * (size_t)bound;
+    for (auto& lane : h->lanes) {
+        for (hipEvent_t* e : {&lane.evIn, &lane.evK, &lane.evOut})
+            if (!*e) MRC_HIP(h, hipEventCreateWithFlags(e, hipEventDisableTiming));
+        if (!lane.pacTotal) {
+            MRC_HIP(h, hipHostMalloc(reinterpret_cast<void**>(&lane.pacTotal), 2 * sizeof(long long), hipHostMallocDefault));
+            lane.pacTotal[0] = lane.pacTotal[1] = 0;
+        }
+        MRC_HIP(h, lane.pcmL.reserve(szPcm));
+        if (joint) MRC_HIP(h, lane.pcmR.reserve(szPcm));
+        MRC_HIP(h, lane.resIn.reserve((size_t)chunk * sizeof(int32_t)));
+        MRC_HIP(h, lane.oScale.reserve((size_t)chunk * nsig * sizeof(int32_t)));
+        MRC_HIP(h, lane.ms.reserve((size_t)chunk * S.nBands * sizeof(int32_t)));
+        MRC_HIP(h, lane.ba.reserve((size_t)chunk * nch * S.nBands * sizeof(int32_t)));
+        MRC_HIP(h, lane.sf.reserve((size_t)chunk * nch * S.nBands * sizeof(int32_t)));
+        MRC_HIP(h, lane.mant.reserve((size_t)chunk * nch * S.halfN * sizeof(uint16_t)));
+        MRC_HIP(h, lane.resOut.reserve((size_t)chunk * sizeof(int32_t)));
+        MRC_HIP(h, lane.pacBytes.reserve(pacCap));
+        MRC_HIP(h, lane.pacOffs.reserve((size_t)(chunk + 1) * sizeof(int64_t)));
+        MRC_HIP(h, lane.pacTable.reserve((size_t)chunk * nch * sizeof(int32_t)));
+        MRC_HIP(h, lane.pacSaved.reserve((size_t)chunk * nch * sizeof(int32_t)));
+    }
+    MRC_HIP(h, h->wsPipe.lines.reserve((size_t)chunk * nsig * S.halfN * sizeof(double)));
+    MRC_HIP(h, h->wsPipe.smr.reserve((size_t)chunk * nsig * S.nBands * sizeof(double)));
+    MRC_HIP(h, h->wsPipe.peak.reserve(alloc_workspace_bytes(S, chunk, joint)));
+    struct DrainAll {
+        mrc_handle* h;
+        ~DrainAll() { for (hipStream_t st : {h->stIn, h->stream, h->stOut}) if (st) (void)hipStreamSynchronize(st); }
+    } drain{h};
+    const bool wasTiming = h->timing;
+    h->timing = false;
+    int rc = MRC_OK;
+    const int64_t nChunks = (n_frames + chunk - 1) / chunk;
+    std::vector<int64_t> base((size_t)nChunks + 1, 0);                      // where every chunk's bytes start in `out`
+#define MRC_Q(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { rc = hip_fail(h, e_, #call); break; } } while (0)
+    // copies chunk c's packed form out, once its size is known (called one chunk behind the queueing loop)
+    auto collect = [&](int64_t c) {
+        Lane& lane = h->lanes[c % kLanes];
+        const int64_t f0 = c * chunk;
+        const int64_t n = (n_frames - f0 < chunk) ? n_frames - f0 : chunk;
+        do {
+            MRC_Q(hipEventSynchronize(lane.evK));
+            const long long total = lane.pacTotal[0];
+            if (lane.pacTotal[1]) { rc = fail(h, MRC_ERR_INVALID, "mrc_encode_stream_pcm16_pac: internal table id out of range"); break; }
+            base[(size_t)c + 1] = base[(size_t)c] + total;
+            if (base[(size_t)c + 1] > out_cap) { rc = fail(h, MRC_ERR_NOMEM, "mrc_encode_stream_pcm16_pac: out_cap too small"); break; }
+            hipStream_t so = h->stOut;
+            MRC_Q(hipMemcpyAsync(out + base[(size_t)c], lane.pacBytes.p, (size_t)total, hipMemcpyDeviceToHost, so));
+            MRC_Q(hipMemcpyAsync(block_offset + f0, lane.pacOffs.p, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToHost, so));
+            if (huff_table)
+                MRC_Q(hipMemcpyAsync(huff_table + f0 * nch, lane.pacTable.p, (size_t)n * nch * sizeof(int32_t), hipMemcpyDeviceToHost, so));
+            if (bits_saved)
+                MRC_Q(hipMemcpyAsync(bits_saved + f0 * nch, lane.pacSaved.p, (size_t)n * nch * sizeof(int32_t), hipMemcpyDeviceToHost, so));
+            if (reservoir_out)
+                MRC_Q(hipMemcpyAsync(reservoir_out + f0, lane.resOut.p, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, so));
+            MRC_Q(hipEventRecord(lane.evOut, so));
+        } while (0);
+    };
+    constexpr int64_t kCollectLag = 2;      // < kLanes - 1: chunk c's buffers are reused by chunk c + kLanes
+    static_assert(kCollectLag < kLanes - 1, "a lane must be collected before it is queued again");
+    static const PackTables tables = [] { PackTables t; pack_tables(&t); return t; }();
+    PackParams P;
+    P.nch = nch; P.joint = joint; P.useHuffman = use_huffman ? 1 : 0;
+    P.nScaleBits = cfg.n_scale_bits; P.nMantSizeBits = cfg.n_mant_size_bits;
+    P.blkBitsA = cfg.blksw_bits_a; P.blkBitsB = cfg.blksw_bits_b;
+    P.bitA = 0; P.bitB = 0;                                                 // long blocks: 1 - a / nMDCTLines = 0
+    MRC_HIP(h, h->packWs.reserve(pack_workspace_bytes(chunk * nch)));
+    for (int64_t c = 0; c < nChunks && rc == MRC_OK; ++c) {
+        Lane& lane = h->lanes[c % kLanes];
+        const bool reused = c >= kLanes;
+        const int64_t f0 = c * chunk;
+        const int64_t n = (n_frames - f0 < chunk) ? n_frames - f0 : chunk;
+        const size_t inBytes = (size_t)(n + 1) * L * sizeof(int16_t);
+        do {
+            if (reused) MRC_Q(hipStreamWaitEvent(h->stIn, lane.evK, 0));
+            MRC_Q(hipMemcpyAsync(lane.pcmL.p, pcm_left + f0 * L, inBytes, hipMemcpyHostToDevice, h->stIn));
+            if (joint) MRC_Q(hipMemcpyAsync(lane.pcmR.p, pcm_right + f0 * L, inBytes, hipMemcpyHostToDevice, h->stIn));
+            if (reservoir_in)
+                MRC_Q(hipMemcpyAsync(lane.resIn.p, reservoir_in + f0, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, h->stIn));
+            MRC_Q(hipEventRecord(lane.evIn, h->stIn));
+            MRC_Q(hipStreamWaitEvent(stK, lane.evIn, 0));
+            if (reused) MRC_Q(hipStreamWaitEvent(stK, lane.evOut, 0));      // (chunk c - kLanes was collected below, kLanes - kCollectLag turns ago)
+            rc = encode_core(h, S, n, lane.pcmL.p, joint ? lane.pcmR.p : nullptr, kSampleI16, L, nullptr,
+                             reservoir_in ? lane.resIn.as<int32_t>() : nullptr, lane.oScale.as<int32_t>(),
+                             lane.ms.as<int32_t>(), lane.ba.as<int32_t>(), lane.sf.as<int32_t>(), lane.mant.p,
+                             MRC_MANTISSA_I16, lane.resOut.as<int32_t>(), nullptr, h->wsPipe, stK);
+            if (rc != MRC_OK) break;
+            MRC_Q(launch_pack(S, P, tables, n, lane.oScale.as<int32_t>(), lane.ms.as<int32_t>(), lane.sf.as<int32_t>(),
+                              lane.ba.as<int32_t>(), lane.mant.p, MRC_MANTISSA_I16, nullptr, lane.pacTable.as<int32_t>(),
+                              lane.pacSaved.as<int32_t>(), lane.pacBytes.as<unsigned char>(), (long long)pacCap,
+                              lane.pacOffs.as<long long>(), h->packWs.p, (int)(bound - 4), stK));
+            MRC_Q(hipMemcpyAsync(&lane.pacTotal[0], pack_total_bytes(h->packWs.p, n * nch), sizeof(long long), hipMemcpyDeviceToHost, stK));
+            MRC_Q(hipMemcpyAsync(&lane.pacTotal[1], pack_error_flag(h->packWs.p, n * nch), sizeof(int), hipMemcpyDeviceToHost, stK));
+            MRC_Q(hipEventRecord(lane.evK, stK));
+        } while (0);
+        if (rc == MRC_OK && c >= kCollectLag) collect(c - kCollectLag);
+    }
+    for (int64_t c = nChunks > kCollectLag ? nChunks - kCollectLag : 0; c < nChunks && rc == MRC_OK; ++c) collect(c);
+#undef MRC_Q
+    h->timing = wasTiming;
+    if (rc != MRC_OK) return rc;
+    for (hipStream_t st : {h->stIn, stK, h->stOut}) MRC_HIP(h, hipStreamSynchronize(st));
+    // the chunks' block offsets count from their own first byte
+    for (int64_t c = 0; c < nChunks; ++c) {
+        const int64_t f0 = c * chunk, n = (n_frames - f0 < chunk) ? n_frames - f0 : chunk;
+        if (base[(size_t)c])
+            for (int64_t i = 0; i < n; ++i) block_offset[f0 + i] += base[(size_t)c];
+    }
+    block_offset[n_frames] = base[(size_t)nChunks];
+    *total_bytes = base[(size_t)nChunks];
     return MRC_OK;
 }
 

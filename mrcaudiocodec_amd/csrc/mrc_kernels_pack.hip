@@ -245,8 +245,9 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup) void pack_write_kernel(
     }
     wave_sync();
     auto prefix_at = [&](int k) { return k < M ? pref[pad16(k)] + laneBase[k / lpl] : pref[pad16(M) + 1]; };
-    // mantissas
-    for (int k = lane; k < M; k += kWave) {
+    // mantissas.  A lane takes a RUN of consecutive lines (the one it scanned): the 64 lanes of one ds_or then hit 64
+    // different words -- with k = lane + 64 j about eight neighbouring lines share a word and the atomics serialise
+    for (int k = lane * lpl, kEnd = min(k + lpl, M); k < kEnd; ++k) {
         const int band = S.bandOfLine[k];
         const int b = ba[band];
         if (b) {

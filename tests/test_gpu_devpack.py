@@ -179,3 +179,45 @@ def test_device_pack_reproduces_the_reference_cli_chunks(env, case, which):
             assert got == ref[int(first[i]):int(last_end[i])], (joint, i, a, b)
             checked += 1
     assert checked == n_blocks
+
+
+@pytest.mark.parametrize("joint", [False, True])
+@pytest.mark.parametrize("use_huffman", [True, False])
+def test_encode_stream_pcm16_pac_equals_encode_then_host_pack(env, joint, use_huffman):
+    """host PCM -> host .pac chunk bytes in one pipelined call (9 chunks over the ring of 4 buffers, the last one short)
+    == mrc_encode_stream_pcm16 followed by the host packer; too small a buffer is reported and retried"""
+    torch, pacfile, enc, cfg = env
+    from mrcaudiocodec_amd import MrcError
+    F = 150
+    rng = np.random.default_rng(11 + joint)
+    level = np.repeat(10.0 ** rng.uniform(-3.5, -0.5, F + 1), 1024)
+    pl = np.clip(np.round(rng.normal(0, 1, (F + 1) * 1024) * level * 32767), -32768, 32767).astype(np.int16)
+    pr = np.clip(np.round(0.8 * pl + 0.2 * rng.normal(0, 1, pl.size) * level * 32767), -32768, 32767).astype(np.int16) if joint else None
+    pl[:1024] = 0
+    if joint:
+        pr[:1024] = 0
+    res_in = rng.integers(-50, 300, F).astype(np.int32)
+    codes = enc.h.encode_stream_pcm16(pl, pr, res_in)
+    if joint:
+        want = pacfile.pack_joint_blocks(cfg, 1024, 1024, codes["overall_scale"], codes["ms_switch"], codes["scale_factor"],
+                                         codes["bit_alloc"], codes["mantissa"], use_huffman)
+    else:
+        want = pacfile.pack_blocks(cfg, 1024, 1024, codes["overall_scale"], codes["scale_factor"], codes["bit_alloc"],
+                                   codes["mantissa"], use_huffman)
+    got = enc.h.encode_stream_pcm16_pac(pl, pr, res_in, use_huffman=use_huffman, chunk_frames=17)
+    assert np.array_equal(got["block_offset"], want[1])
+    assert np.array_equal(got["bytes"], want[0])
+    assert np.array_equal(got["huff_table"], want[2])
+    assert np.array_equal(got["bits_saved"], want[3])
+    assert np.array_equal(got["reservoir_out"], codes["reservoir_out"])
+    one = enc.h.encode_stream_pcm16_pac(pl, pr, res_in, use_huffman=use_huffman)          # default chunking: one chunk here
+    assert np.array_equal(one["bytes"], want[0]) and np.array_equal(one["block_offset"], want[1])
+    small = enc.h.encode_stream_pcm16_pac(pl, pr, res_in, use_huffman=use_huffman, chunk_frames=40, bytes_per_chunk=16)
+    assert np.array_equal(small["bytes"], want[0])                                        # retried at the worst-case size
+    import ctypes as C
+    from mrcaudiocodec_amd import _lib
+    tiny, offs, total = np.zeros(64, np.uint8), np.zeros(F + 1, np.int64), np.zeros(1, np.int64)
+    vp = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    rc = _lib.lib.mrc_encode_stream_pcm16_pac(enc.h._h, F, vp(pl), vp(pr), vp(res_in), int(use_huffman), vp(tiny), tiny.size,
+                                              vp(offs), None, None, None, total.ctypes.data_as(_lib._i64p), 17)
+    assert rc == _lib.MRC_ERR_NOMEM and not tiny.any()                                    # reported, nothing written

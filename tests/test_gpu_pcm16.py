@@ -106,7 +106,7 @@ def test_encode_stream_pcm16_pipeline(h, joint, pinned):
         out = {}
         for k, (shape, dt) in shapes.items():
             p = PinnedArray(shape, dt); keep.append(p); out[k] = p.array
-    got = h.encode_stream_pcm16(pl, pr, res_in, chunk_frames=17, out=out)          # 9 chunks over the 3 lanes
+    got = h.encode_stream_pcm16(pl, pr, res_in, chunk_frames=17, out=out)          # 9 chunks over the ring of 4 chunk buffers
     bl = np.array(fast.blocks_from_stream(G.pcm_to_float(pl), 1024))
     if joint:
         br = np.array(fast.blocks_from_stream(G.pcm_to_float(pr), 1024))
