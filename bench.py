@@ -534,6 +534,8 @@ def main():
         pack = host_pack_rate(np, ppac, out, min(Fs, 16384), threads=max(1, min(16, (os.cpu_count() or 8) // world)))
         pack_rate = pack["huffman_priced_on_host_Msamples_s"]
         slowest = -max_over_ranks(-pack_rate, coll_device)            # min over ranks
+        dpack = device_pack_rate(torch, enc, out, Fs, args.steps)
+        dslow = -max_over_ranks(-dpack["huffman_priced_on_device_Msamples_s"], coll_device)
         if rank == 0:
             line["configs4"] = {
                 "workload": "configs[4]: C3 stereo content as ONE stream of %d frames, frame-sharded x%d (contiguous ranges, "
@@ -541,6 +543,9 @@ def main():
                 "value": round(2.0 * Fs * HOP * world * args.steps / es / 1e6, 3), "unit": "Msamples/s",
                 "frames_per_gpu_per_step": Fs, "ms_per_step": round(es / args.steps * 1e3, 4),
                 "host_pack_Msamples_s": round(slowest * world, 1),
+                "device_pack_Msamples_s": round(dslow * world, 1),
+                "device_pack": dict(dpack, note="the same back end on each rank's GPU (mrc_dev_pack_blocks); whole-job figure = "
+                                                "world x the slowest rank's rate"),
                 "host_pack": dict(pack, note="Huffman table choice + bit packing of each rank's outputs on its share of the "
                                              "host cores (C++, csrc/mrc_pack.cpp), outside the timed GPU region; whole-job "
                                              "figure = world x the slowest rank's rate")}
