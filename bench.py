@@ -521,6 +521,36 @@ def main():
                                              "traffic": None if "smr_kernel" not in tb else round(tb["smr_kernel"] * hops),
                                              "traffic_note": "smr_kernel, all four block shapes of a step together"}),
             "hbm_traffic_bytes_per_hop": {k: v for k, v in tb.items()} or None, "kernels": rows_b}
+        # ---- stream mode: MANY stereo streams advance one block per step, every stream's bit reservoir chained through the
+        # Huffman savings of its previous block on the device (codecThem.py:224,274) -- the mode that writes the files the
+        # reference writes; a step's batch is the number of streams, not the length of one
+        nS, nT = 8192, 12
+        gs = torch.Generator(device=device)
+        gs.manual_seed(7)
+        pl = torch.clamp(torch.round(torch.randn((nS, (nT + 1) * HOP), generator=gs, device=device, dtype=torch.float64) * 3000),
+                         -32767, 32767)
+        ssl = (torch.sign(pl) * 2.0 * torch.abs(pl) / 65535).contiguous()
+        ssl[:, :HOP] = 0
+        ssr = (0.7 * ssl + 0.3 * torch.roll(ssl, 17, dims=1)).contiguous()
+        ssr[:, :HOP] = 0
+        del pl
+        one = np.array([(i * HOP, HOP, HOP) for i in range(nT)], dtype=np.int64)
+        shapes_all = np.broadcast_to(one, (nS, nT, 3))
+        # warm-up with the WHOLE schedule: every step keeps its outputs (the packer reads them afterwards), 70 MB each --
+        # the caching allocator then holds the blocks the timed run takes again
+        warm = enc.encode_chained(ssl, ssr, shapes_all)
+        del warm
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        _, reservoir = enc.encode_chained(ssl, ssr, shapes_all)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        cfgs["stream_mode"] = {
+            "workload": "%d stereo streams x %d chained joint long blocks, bit reservoirs carried from block to block on the "
+                        "device (encode kernels + Huffman pricing per step)" % (nS, nT),
+            "value": round(2.0 * nS * nT * HOP / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3 / nT, 4),
+            "mean_final_reservoir_bits": round(float(reservoir.double().mean().item()), 1)}
+        del ssl, ssr
         line["configs"] = cfgs
         del xs, groups
 

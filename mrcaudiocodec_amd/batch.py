@@ -118,11 +118,11 @@ class StreamEncoder:
 
     def encode_chained(self, left, right, shapes, use_huffman=True):
         """Stream mode for MANY stereo streams at once: left/right [nStreams][samples] on the device (each row
-        starts with its zero prior hop), shapes[s] = the (offset, a, b) sequence of stream s.  Step t encodes the
+        starts with its zero prior hop), shapes[s] = the (offset, a, b) sequence of stream s (lists, or ONE int64 array [nStreams][nBlocks][3]).  Step t encodes the
         t-th block of every stream that still has one, grouped by block shape; the bit reservoir of each stream
         is chained from block to block ON THE DEVICE (reservoir_out + Huffman bits_saved, codecThem.py:274,503),
         so there is no host round trip inside the loop.  Returns (steps, reservoir): steps = list of
-        (stream ids (list), a, b, outputs dict of device tensors) in encode order; reservoir [nStreams] int32."""
+        (stream ids (int64 array), a, b, outputs dict of device tensors) in encode order; reservoir [nStreams] int32."""
         import numpy as np
         nS, stride = left.shape[0], left.shape[1]
         if right.shape != left.shape or len(shapes) != nS:
@@ -131,20 +131,35 @@ class StreamEncoder:
         reservoir = torch.zeros((nS,), dtype=torch.int32, device=self.device)
         # the schedule (which streams take which block shape at which step) is host logic on the shape lists: built
         # with NumPy and uploaded BEFORE the loop, so the loop itself only queues kernels
-        nT = max((len(s) for s in shapes), default=0)
-        tab = np.full((nS, nT, 3), -1, dtype=np.int64)
-        for s, sh in enumerate(shapes):
-            if len(sh):
-                tab[s, :len(sh)] = np.asarray(sh, dtype=np.int64)
+        tab = None
+        if isinstance(shapes, np.ndarray) and shapes.ndim == 3 and shapes.shape[2] == 3:
+            tab = np.ascontiguousarray(shapes, dtype=np.int64)   # the schedule as an array [nStreams][nBlocks][3]: no Python loop
+            nT = tab.shape[1]                                    # (rows of (-1, -1, -1) pad shorter streams)
+        else:
+            nT = max((len(s) for s in shapes), default=0)
+        if tab is None and nT and all(len(s) == nT for s in shapes):   # equally long streams: one conversion
+            try:
+                tab = np.asarray(shapes, dtype=np.int64)
+                if tab.shape != (nS, nT, 3):
+                    tab = None
+            except (ValueError, TypeError):
+                tab = None
+        if tab is None:
+            tab = np.full((nS, nT, 3), -1, dtype=np.int64)
+            for s, sh in enumerate(shapes):
+                if len(sh):
+                    tab[s, :len(sh)] = np.asarray(sh, dtype=np.int64)
         if nT and (tab[:, :, 0] + tab[:, :, 1] + tab[:, :, 2] > stride).any():
             raise ValueError("a stream is too short for one of its blocks")
         plan = []
         for t in range(nT):
             live = tab[:, t, 1] > 0
-            for (a, b) in sorted(set(map(tuple, tab[live, t, 1:3].tolist()))):
-                ids = np.nonzero(live & (tab[:, t, 1] == a) & (tab[:, t, 2] == b))[0]
+            code = tab[:, t, 1] * (1 << 32) + tab[:, t, 2]                    # (a, b) as one sortable key
+            for key in np.unique(code[live]).tolist():
+                a, b = key >> 32, key & 0xffffffff
+                ids = np.nonzero(live & (code == key))[0]
                 plan.append((int(a), int(b), ids, ids * stride + tab[ids, t, 0]))
-        dev_plan = [(a, b, ids.tolist(), torch.from_numpy(ids).to(self.device), torch.from_numpy(offs).to(self.device))
+        dev_plan = [(a, b, ids, torch.from_numpy(ids).to(self.device), torch.from_numpy(offs).to(self.device))
                     for (a, b, ids, offs) in plan]
         steps = []
         for (a, b, ids, idx, offs) in dev_plan:

@@ -430,6 +430,33 @@ def test_pac_bytes_many_streams_chained_on_device(h, huff):
     assert got[1] == ppac.encode_stereo_stream(h, streams[1], shapes[1], use_huffman=huff)
 
 
+@pytest.mark.gpu
+def test_chained_schedule_as_array_equals_lists(h):
+    # StreamEncoder.encode_chained takes the schedule as per-stream lists or as ONE int64 array [nStreams][nBlocks][3]
+    # (rows of -1 pad shorter streams): same steps, same integers, same final reservoirs
+    torch = pytest.importorskip("torch")
+    from mrcaudiocodec_amd import synth
+    from mrcaudiocodec_amd.batch import StreamEncoder
+    enc = StreamEncoder(handle=h)
+    hops = 7
+    nS = 5
+    rows = [np.concatenate([np.zeros(1024), synth.c2_noise(hops, seed=30 + s, sigma=0.02 * (s + 1))[:hops * 1024]]) for s in range(nS)]
+    left = torch.as_tensor(np.stack(rows), device=enc.device)
+    right = (0.6 * left + 0.4 * torch.roll(left, 5, dims=1)).contiguous()
+    right[:, :1024] = 0
+    lists = [[(i * 1024, 1024, 1024) for i in range(hops - 1 - (s % 2))] for s in range(nS)]
+    arr = np.full((nS, hops - 1, 3), -1, dtype=np.int64)
+    for s, sh in enumerate(lists):
+        arr[s, :len(sh)] = sh
+    sa, ra = enc.encode_chained(left, right, lists)
+    sb, rb = enc.encode_chained(left, right, arr)
+    assert torch.equal(ra, rb) and len(sa) == len(sb)
+    for (ia, a1, b1, oa), (ib, a2, b2, ob) in zip(sa, sb):
+        assert (a1, b1) == (a2, b2) and np.array_equal(np.asarray(ia), np.asarray(ib))
+        for k in ("overall_scale", "ms_switch", "scale_factor", "bit_alloc", "mantissa", "huff_table"):
+            assert torch.equal(oa[k], ob[k]), k
+
+
 def test_device_offsets_odd_and_even_long_blocks(h):
     # explicit offsets into a device stream for LONG blocks (the wave-per-frame MDCT kernel): even offsets take
     # 16-byte loads, odd ones the 8-byte path; mono and joint
