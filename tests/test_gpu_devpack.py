@@ -221,3 +221,33 @@ def test_encode_stream_pcm16_pac_equals_encode_then_host_pack(env, joint, use_hu
     rc = _lib.lib.mrc_encode_stream_pcm16_pac(enc.h._h, F, vp(pl), vp(pr), vp(res_in), int(use_huffman), vp(tiny), tiny.size,
                                               vp(offs), None, None, None, total.ctypes.data_as(_lib._i64p), 17)
     assert rc == _lib.MRC_ERR_NOMEM and not tiny.any()                                    # reported, nothing written
+
+
+def test_device_pack_with_other_field_widths():
+    """field widths other than the defaults (3-bit scale factors, 2 + 0 block-switching bits): crafted codes, device == host"""
+    import torch
+    from mrcaudiocodec_amd import pacfile
+    from mrcaudiocodec_amd.batch import StreamEncoder
+    enc = StreamEncoder(device_id=0, n_scale_bits=3, blksw_bits_a=2, blksw_bits_b=0)
+    c = enc.h.cfg
+    cfg = pacfile.make_config(c.sample_rate, c.n_mdct_lines, c.n_short, c.n_scale_bits, c.n_mant_size_bits,
+                              c.target_bits_per_sample, c.blksw_bits_a, c.blksw_bits_b)
+    rng = np.random.default_rng(77)
+    for (a, b) in ((1024, 1024), (128, 128)):
+        lines = enc.h.bands(a, b)
+        nb, half = len(lines), (a + b) // 2
+        n = 40
+        for joint in (False, True):
+            nch = 2 if joint else 1
+            ba = rng.integers(0, 17, (n, nch, nb)).astype(np.int32)
+            ba[ba == 1] = 0
+            sf = rng.integers(0, 8, (n, nch, nb)).astype(np.int32)
+            bits = ba[:, :, np.repeat(np.arange(nb), lines)]
+            mant = ((rng.integers(0, 1 << 16, bits.shape) % 40) & ((1 << bits) - 1)).astype(np.int32)
+            out = {"overall_scale": _dev(torch, rng.integers(0, 8, (n, 4 if joint else 1)), torch.int32),
+                   "scale_factor": _dev(torch, sf, torch.int32), "bit_alloc": _dev(torch, ba, torch.int32),
+                   "mantissa": _dev(torch, mant, torch.int32)}
+            if joint:
+                out["ms_switch"] = _dev(torch, rng.integers(0, 2, (n, nb)), torch.int32)
+            for use_huffman in (True, False):
+                _check(torch, pacfile, enc, cfg, a, b, joint, out, use_huffman)
