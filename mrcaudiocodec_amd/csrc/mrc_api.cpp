@@ -778,8 +778,7 @@ int mrc_encode_stream_pcm16_pac(mrc_handle* h, int64_t n_frames, const int16_t* 
                               lane.ba.as<int32_t>(), lane.mant.p, MRC_MANTISSA_I16, nullptr, lane.pacTable.as<int32_t>(),
                               lane.pacSaved.as<int32_t>(), lane.pacBytes.as<unsigned char>(), (long long)pacCap,
                               lane.pacOffs.as<long long>(), h->packWs.p, (int)(bound - 4), stK));
-            MRC_Q(hipMemcpyAsync(&lane.pacTotal[0], pack_total_bytes(h->packWs.p, n * nch), sizeof(long long), hipMemcpyDeviceToHost, stK));
-            MRC_Q(hipMemcpyAsync(&lane.pacTotal[1], pack_error_flag(h->packWs.p, n * nch), sizeof(int), hipMemcpyDeviceToHost, stK));
+            MRC_Q(launch_pack_export(h->packWs.p, n * nch, lane.pacTotal, stK));   // 16 bytes, written by a kernel: no copy command
             MRC_Q(hipEventRecord(lane.evK, stK));
         } while (0);
         if (rc == MRC_OK && c >= kCollectLag) collect(c - kCollectLag);

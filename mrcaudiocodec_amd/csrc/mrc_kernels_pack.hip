@@ -21,6 +21,8 @@
 
 namespace mrc {
 using namespace dev;
+const int* pack_error_flag(const void* ws, int64_t nChunks);
+const long long* pack_total_bytes(const void* ws, int64_t nChunks);
 namespace {
 
 constexpr int kWavesPerGroup = 4;
@@ -269,7 +271,21 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup) void pack_write_kernel(
     for (int j = lane; j < nBytes; j += kWave) dst[4 + j] = (unsigned char)((w[j >> 2] >> (24 - 8 * (j & 3))) & 255u);
 }
 
+// total and error flag straight into page-locked host memory (device-visible): no copy command on the kernel stream
+__global__ void pack_export_kernel(const long long* __restrict__ total, const int* __restrict__ errorFlag,
+                                   long long* __restrict__ hostOut) {
+    if (threadIdx.x || blockIdx.x) return;
+    hostOut[0] = *total;
+    hostOut[1] = *errorFlag;
+    __threadfence_system();
+}
+
 }  // namespace
+
+hipError_t launch_pack_export(const void* ws, int64_t nChunks, long long* hostOut, hipStream_t st) {
+    hipLaunchKernelGGL(pack_export_kernel, dim3(1), dim3(64), 0, st, pack_total_bytes(ws, nChunks), pack_error_flag(ws, nChunks), hostOut);
+    return hipGetLastError();
+}
 
 size_t pack_workspace_bytes(int64_t nChunks) {
     const int64_t nTiles = (nChunks + kScanTile - 1) / kScanTile;
