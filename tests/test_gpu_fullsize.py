@@ -1,0 +1,145 @@
+"""
+GPU tests at the FULL batch sizes of BASELINE.json's configurations (2^20 mono frames per GPU; configs[4]'s
+10^7 stereo frames over 8 GPUs = 1.25 * 10^6 per GPU, here 2^19 joint frames), where the oracle would take days: the
+size-independent properties of the path instead --
+
+  * sharding / linearity: the batch encoded in one launch set == the same stream cut into contiguous shards (each with its
+    one-hop halo, as a rank would hold it) and encoded shard by shard;
+  * idempotence: a second run gives the same integers (no run-to-run nondeterminism in the reductions);
+  * sortedness + a checksum of checksums: the device packer's block offsets increase strictly, their differences are the
+    chunk sizes, the length fields scanned from the packed bytes on the host add up to the total;
+  * encode -> pack -> parse round trip on a sample of blocks spread over the whole batch: the host parser reads back
+    exactly the integers the encoder produced.
+
+A sample of the same frames is also checked against the oracle (the content is bench.py's counter-based stream, so any
+slice can be regenerated on its own).  Everything goes through the C ABI.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HOP = 1024
+
+
+def _whole_stream(torch, bench, dev, kind, n_frames, piece=1 << 17):
+    """int16 stream(s) of n_frames + 1 hops, generated on the device piece by piece (counter-based content)."""
+    first = bench.stream_slice(torch, dev, kind, 0, 1)
+    chans = [torch.empty(((n_frames + 1) * HOP,), dtype=torch.int16, device=dev) for _ in first]
+    for f0 in range(0, n_frames, piece):
+        n = min(piece, n_frames - f0)
+        for ch, part in zip(chans, bench.stream_slice(torch, dev, kind, f0, n)):
+            ch[f0 * HOP:(f0 + n + 1) * HOP] = part
+    return chans
+
+
+def _properties(torch, enc, pacfile, cfg, chans, n_frames, world, joint, oracle_check):
+    from mrcaudiocodec_amd.shard import shard_frames, shard_samples
+    L = HOP
+    left, right = chans[0], (chans[1] if joint else None)
+    keys = ("overall_scale", "bit_alloc", "scale_factor", "mantissa", "reservoir_out") + (("ms_switch",) if joint else ())
+    whole = {k: v.clone() for k, v in enc.encode_long(left, right, n_frames, mantissa16=True).items()}
+    # idempotence
+    again = enc.encode_long(left, right, n_frames, mantissa16=True)
+    for k in keys:
+        assert torch.equal(whole[k], again[k]), "second run differs: " + k
+    # sharding: every rank's slice on its own == its rows of the whole batch
+    for rank in range(world):
+        f0, n = shard_frames(n_frames, world, rank)
+        s0, s1 = shard_samples(f0, n, L)
+        part = enc.encode_long(left[s0:s1].contiguous(), None if right is None else right[s0:s1].contiguous(), n, mantissa16=True)
+        for k in keys:
+            assert torch.equal(part[k], whole[k][f0:f0 + n]), "shard %d differs: %s" % (rank, k)
+    # device packer: sortedness and the checksum of checksums
+    packed = enc.pack(L, L, whole, use_huffman=True)
+    offs = packed["block_offset"]
+    sizes = offs[1:] - offs[:-1]
+    assert int(offs[0].item()) == 0 and bool((sizes > 0).all())
+    total = int(offs[-1].item())
+    assert total == packed["bytes"].numel()
+    raw = packed["bytes"].cpu().numpy()
+    nch = 2 if joint else 1
+    # scan on the host: the 4-byte length fields chain through the whole byte string and end exactly at its end
+    from mrcaudiocodec_amd import _lib
+    n_chunks = _lib.lib.mrc_pac_scan_chunks(raw.ctypes.data_as(_lib._u8p), raw.size, 0, None, 0)
+    assert n_chunks == n_frames * nch
+    starts = np.zeros(n_chunks, dtype=np.int64)
+    _lib.lib.mrc_pac_scan_chunks(raw.ctypes.data_as(_lib._u8p), raw.size, 0, starts.ctypes.data_as(_lib._i64p), n_chunks)
+    assert np.array_equal(starts[0::nch], offs[:-1].cpu().numpy())
+    # encode -> pack -> parse round trip on blocks spread over the batch
+    rng = np.random.default_rng(5)
+    sample = np.unique(np.concatenate([[0, n_frames - 1], rng.integers(0, n_frames, 2046)]))
+    sel = np.stack([starts[sample * nch + c] for c in range(nch)], axis=1).reshape(-1)
+    parsed = pacfile.unpack_blocks(cfg, raw, sel, nch, joint)
+    nb = whole["bit_alloc"].shape[-1]
+    idx = torch.as_tensor(sample, device=whole["bit_alloc"].device)
+    host = {k: whole[k][idx].cpu().numpy() for k in keys}
+    assert np.array_equal(parsed["bit_alloc"][:, :, :nb], host["bit_alloc"])
+    live = host["bit_alloc"] > 0                                     # (the writer stores a scale factor for every band; the
+    assert np.array_equal(parsed["scale_factor"][:, :, :nb], host["scale_factor"])   # encoder's are defined for all of them)
+    assert np.array_equal(parsed["mantissa"], host["mantissa"].view(np.uint16).astype(np.int32))
+    assert np.array_equal(parsed["overall_scale"], host["overall_scale"])
+    if joint:
+        assert np.array_equal(parsed["ms_switch"][:, :nb], host["ms_switch"])
+    assert np.array_equal(parsed["huff_table"], packed["huff_table"][idx].cpu().numpy())
+    assert live.any()
+    # ... and a few of the same frames against the oracle
+    oracle_check(sample[:: max(1, len(sample) // 24)][:24], host, sample)
+
+
+def _env(sample_rate=48000):
+    import torch
+    import bench
+    from mrcaudiocodec_amd import pacfile
+    from mrcaudiocodec_amd.batch import StreamEncoder
+    enc = StreamEncoder(device_id=0)
+    c = enc.h.cfg
+    cfg = pacfile.make_config(c.sample_rate, c.n_mdct_lines, c.n_short, c.n_scale_bits, c.n_mant_size_bits,
+                              c.target_bits_per_sample, c.blksw_bits_a, c.blksw_bits_b)
+    return torch, bench, pacfile, enc, cfg
+
+
+def test_full_size_mono_batch_properties():
+    """configs[1] at SURVEY 8(d)'s size: 2^20 long mono frames of the bench's white-noise stream on one GPU"""
+    import refgold as G
+    from oracle import fast
+    torch, bench, pacfile, enc, cfg = _env()
+    dev = torch.device("cuda", 0)
+    F = 1 << 20
+    chans = _whole_stream(torch, bench, dev, "c2", F)
+
+    def oracle_check(frames, host, sample):
+        pos = {int(f): i for i, f in enumerate(sample)}
+        for f in frames:
+            (pcm,) = bench.stream_slice(torch, dev, "c2", int(f), 1)
+            blocks = np.array(fast.blocks_from_stream(G.pcm_to_float(pcm.cpu().numpy()), HOP))
+            want = fast.encode_mono_batch(blocks, HOP, HOP)
+            i = pos[int(f)]
+            for k in ("overall_scale", "bit_alloc", "scale_factor", "reservoir_out"):
+                assert np.array_equal(np.squeeze(host[k][i]).astype(np.int64), np.squeeze(want[k][0]).astype(np.int64)), (f, k)
+            assert np.array_equal(host["mantissa"][i, 0].view(np.uint16).astype(np.int64), np.squeeze(want["mantissa"][0]).astype(np.int64)), f
+
+    _properties(torch, enc, pacfile, cfg, chans, F, 8, False, oracle_check)
+
+
+def test_full_size_joint_batch_properties():
+    """configs[2] / the per-GPU share of configs[4]: 2^19 long joint stereo frames (C3 content), 8 shards"""
+    import refgold as G
+    from oracle import fast
+    torch, bench, pacfile, enc, cfg = _env()
+    dev = torch.device("cuda", 0)
+    F = 1 << 19
+    chans = _whole_stream(torch, bench, dev, "c3", F)
+
+    def oracle_check(frames, host, sample):
+        pos = {int(f): i for i, f in enumerate(sample)}
+        for f in frames:
+            sl, sr = bench.stream_slice(torch, dev, "c3", int(f), 1)
+            bl = np.array(fast.blocks_from_stream(G.pcm_to_float(sl.cpu().numpy()), HOP))
+            br = np.array(fast.blocks_from_stream(G.pcm_to_float(sr.cpu().numpy()), HOP))
+            want = fast.encode_joint_batch(bl, br, HOP, HOP)
+            i = pos[int(f)]
+            for k in ("overall_scale", "ms_switch", "bit_alloc", "scale_factor", "reservoir_out"):
+                assert np.array_equal(np.squeeze(host[k][i]).astype(np.int64), np.squeeze(want[k][0]).astype(np.int64)), (f, k)
+            assert np.array_equal(host["mantissa"][i].view(np.uint16).astype(np.int64), np.squeeze(want["mantissa"][0]).astype(np.int64)), f
+
+    _properties(torch, enc, pacfile, cfg, chans, F, 8, True, oracle_check)
