@@ -251,3 +251,34 @@ def test_device_pack_with_other_field_widths():
                 out["ms_switch"] = _dev(torch, rng.integers(0, 2, (n, nb)), torch.int32)
             for use_huffman in (True, False):
                 _check(torch, pacfile, enc, cfg, a, b, joint, out, use_huffman)
+
+
+def test_stream_entry_points_on_empty_and_single_frame_streams(env):
+    """n = 0 (only the prior hop) and n = 1 through both pipelined entry points, mono and stereo"""
+    torch, pacfile, enc, cfg = env
+    from oracle import fast
+    rng = np.random.default_rng(3)
+    for joint in (False, True):
+        for n in (0, 1):
+            pl = np.concatenate([np.zeros(1024), rng.normal(0, 3000, n * 1024)]).round().astype(np.int16)
+            pr = np.concatenate([np.zeros(1024), rng.normal(0, 2000, n * 1024)]).round().astype(np.int16) if joint else None
+            codes = enc.h.encode_stream_pcm16(pl, pr)
+            pac = enc.h.encode_stream_pcm16_pac(pl, pr, use_huffman=True)
+            assert codes["mantissa"].shape == (n, 2 if joint else 1, 1024)
+            assert pac["block_offset"].shape == (n + 1,) and pac["block_offset"][0] == 0
+            if n == 0:
+                assert pac["bytes"].size == 0
+                continue
+            bl = np.array(fast.blocks_from_stream(G.pcm_to_float(pl), 1024))
+            if joint:
+                br = np.array(fast.blocks_from_stream(G.pcm_to_float(pr), 1024))
+                want = fast.encode_joint_batch(bl, br, 1024, 1024)
+                host = pacfile.pack_joint_blocks(cfg, 1024, 1024, codes["overall_scale"], codes["ms_switch"],
+                                                 codes["scale_factor"], codes["bit_alloc"], codes["mantissa"], True)
+            else:
+                want = fast.encode_mono_batch(bl, 1024, 1024)
+                host = pacfile.pack_blocks(cfg, 1024, 1024, codes["overall_scale"], codes["scale_factor"], codes["bit_alloc"],
+                                           codes["mantissa"], True)
+            assert np.array_equal(np.squeeze(codes["mantissa"]).astype(np.int64), np.squeeze(want["mantissa"]).astype(np.int64))
+            assert np.array_equal(np.squeeze(codes["bit_alloc"]), np.squeeze(want["bit_alloc"]))
+            assert np.array_equal(pac["bytes"], host[0]) and pac["block_offset"][1] == host[0].size
