@@ -120,6 +120,11 @@ int get_shape(mrc_handle* h, int a, int b, const HostShape** out) {
     return MRC_OK;
 }
 
+bool all_bands_non_empty(const HostShape& hs) {
+    for (int n : hs.bandN) if (n <= 0) return false;
+    return true;
+}
+
 hipStream_t pick_stream(mrc_handle* h, void* stream) { return stream ? (hipStream_t)stream : h->stream; }
 
 }  // namespace
@@ -371,7 +376,7 @@ int mrc_dev_pack_blocks(mrc_handle* h, int a, int b, int64_t n_blocks, int n_cha
     const int bound = (int)(mrc_pack_bound(&cfg, a, b, 1, joint) - 4);
     MRC_HIP(h, launch_pack(S, P, tables, n_blocks, overall_scale, ms_switch, scale_factor, bit_alloc, mantissa,
                            mantissa_format, huff_table_in, tableOut, bits_saved, out, (long long)out_cap,
-                           reinterpret_cast<long long*>(block_offset), h->packWs.p, bound, st));
+                           reinterpret_cast<long long*>(block_offset), h->packWs.p, bound, all_bands_non_empty(*hs), st));
     if (total_bytes) {                                 // the caller wants the size now: one synchronisation
         long long total = 0;
         int bad = 0;
@@ -777,7 +782,7 @@ int mrc_encode_stream_pcm16_pac(mrc_handle* h, int64_t n_frames, const int16_t* 
             MRC_Q(launch_pack(S, P, tables, n, lane.oScale.as<int32_t>(), lane.ms.as<int32_t>(), lane.sf.as<int32_t>(),
                               lane.ba.as<int32_t>(), lane.mant.p, MRC_MANTISSA_I16, nullptr, lane.pacTable.as<int32_t>(),
                               lane.pacSaved.as<int32_t>(), lane.pacBytes.as<unsigned char>(), (long long)pacCap,
-                              lane.pacOffs.as<long long>(), h->packWs.p, (int)(bound - 4), stK));
+                              lane.pacOffs.as<long long>(), h->packWs.p, (int)(bound - 4), all_bands_non_empty(*hs), stK));
             MRC_Q(launch_pack_export(h->packWs.p, n * nch, lane.pacTotal, stK));   // 16 bytes, written by a kernel: no copy command
             MRC_Q(hipEventRecord(lane.evK, stK));
         } while (0);

@@ -121,7 +121,8 @@ hipError_t launch_pack(const DevShape& S, const PackParams& P, const PackTables&
                        const int* msSwitch, const int* scaleFactor, const int* bitAlloc, const void* mant, int mantFmt,
                        const int* tableIn /* nullable */, int* tableOut, int* bitsSaved /* nullable */, unsigned char* out,
                        long long outCap, long long* blockOffset /* [nBlocks + 1] */, void* ws /* pack_workspace_bytes */,
-                       int boundBytes /* largest chunk payload */, hipStream_t st);
+                       int boundBytes /* largest chunk payload */, bool allBandsNonEmpty /* of this shape's table */,
+                       hipStream_t st);
 hipError_t launch_pack_export(const void* ws, int64_t nChunks, long long* hostOut /* page-locked: {total, error flag} */,
                               hipStream_t st);
 const int* pack_error_flag(const void* ws, int64_t nChunks);          // device addresses inside ws

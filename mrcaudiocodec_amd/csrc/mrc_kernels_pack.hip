@@ -70,8 +70,9 @@ template <class MantT>
 __global__ __launch_bounds__(kWave * kWavesPerGroup) void pack_plan_kernel(
     DevShape S, PackParams P, PackTables T, int64_t nChunks, const int* __restrict__ bitAlloc,
     const MantT* __restrict__ mant, const int* __restrict__ tableIn, int* __restrict__ tableOut,
-    int* __restrict__ bitsSaved, int* __restrict__ chunkBytes, int* __restrict__ errorFlag) {
+    int* __restrict__ bitsSaved, int* __restrict__ chunkBytes, int* __restrict__ errorFlag, int fast16) {
     __shared__ unsigned sEmit[4 * (kPackLutSize + 1)];
+    __shared__ int sBa[kWavesPerGroup * kMaxBands];
     for (int i = threadIdx.x; i < 4 * (kPackLutSize + 1); i += blockDim.x) sEmit[i] = T.emit[i];
     __syncthreads();
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
@@ -84,19 +85,51 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup) void pack_plan_kernel(
     // code + the raw mantissa, the escape VALUE itself its code alone) and what the WRITER emits for it (194-200: the
     // escape value is followed by its raw mantissa too)
     int raw = 0, cost[4] = {0, 0, 0, 0}, wr[4] = {0, 0, 0, 0};
-    for (int k = lane; k < M; k += kWave) {
-        const int b = ba[S.bandOfLine[k]];
-        if (b) {
-            const unsigned idx = lut_index((int)m[k]);
-            raw += b;
+    auto price = [&](int v, int b) {
+        const unsigned idx = lut_index(v);
+        raw += b;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const unsigned e = sEmit[t * (kPackLutSize + 1) + idx];
-                const int n = (int)((e >> 16) & 0x7fffu);
-                const bool follows = (e >> 31) != 0;
-                wr[t] += n + (follows ? b : 0);
-                cost[t] += n + ((follows && (int)idx != T.escape[t]) ? b : 0);
+        for (int t = 0; t < 4; ++t) {
+            const unsigned e = sEmit[t * (kPackLutSize + 1) + idx];
+            const int n = (int)((e >> 16) & 0x7fffu);
+            const bool follows = (e >> 31) != 0;
+            wr[t] += n + (follows ? b : 0);
+            cost[t] += n + ((follows && (int)idx != T.escape[t]) ? b : 0);
+        }
+    };
+    if (fast16) {
+        // 1024-line chunks: 16 consecutive lines per lane -- one 16-byte load of their bands, two / four of their
+        // mantissas, the bit allocation staged in LDS (see pack_write_kernel)
+        int* baL = sBa + wave * kMaxBands;
+        if (lane < nb) baL[lane] = ba[lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int k0 = 16 * lane;
+        const uint4 bw = *reinterpret_cast<const uint4*>(S.bandOfLine + k0);
+        const unsigned bwv[4] = {bw.x, bw.y, bw.z, bw.w};
+        int v[16];
+        if (sizeof(MantT) == 2) {
+            const uint4 a0 = *reinterpret_cast<const uint4*>(m + k0), a1 = *reinterpret_cast<const uint4*>(m + k0 + 8);
+            const unsigned aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = (int)((aw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int4 a = *reinterpret_cast<const int4*>(m + k0 + 4 * q);
+                v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
             }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int b = baL[(bwv[j >> 2] >> (8 * (j & 3))) & 0xffu];
+            if (b) price(v[j], b);
+        }
+    } else {
+        for (int k = lane; k < M; k += kWave) {
+            const int b = ba[S.bandOfLine[k]];
+            if (b) price((int)m[k], b);
         }
     }
     raw = wave_sum_i(raw);
@@ -185,7 +218,8 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup) void pack_write_kernel(
     DevShape S, PackParams P, PackTables T, int64_t nChunks, const int* __restrict__ oscale,
     const int* __restrict__ msSwitch, const int* __restrict__ scaleFactor, const int* __restrict__ bitAlloc,
     const MantT* __restrict__ mant, const int* __restrict__ table, const int* __restrict__ chunkBytes,
-    const long long* __restrict__ pos, unsigned char* __restrict__ out, long long outCap, int wordsPerWave) {
+    const long long* __restrict__ pos, unsigned char* __restrict__ out, long long outCap, int wordsPerWave,
+    int fast16 /* 1024 lines, every band non-empty, planes 16-byte aligned */) {
     extern __shared__ unsigned smem[];
     unsigned* sEmit = smem;                                                     // [4 (kPackLutSize + 1)]
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
@@ -226,6 +260,62 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup) void pack_write_kernel(
     } else {
         if (lane == 0) put_bits(w, hdr, (unsigned)oscale[blk * P.nch + ch] & scaleMask, P.nScaleBits);
         hdr += P.nScaleBits;
+    }
+    // FAST PATH, 1024-line chunks (the long blocks: nearly all of a stream): a lane owns 16 CONSECUTIVE lines from the
+    // start -- their bands are one 16-byte load, their mantissas two (uint16) or four (int32), codes, lengths and the
+    // prefix over the 16 stay in registers, only the 64 lane totals are scanned across the wave and only the band starts
+    // go through LDS (for the band headers).  No second pass over the mantissas, no length array in LDS.
+    if (fast16) {
+        int* baL = laneBase;                                                    // [32] bit allocation per band
+        int* bandPref = laneBase + 32;                                          // [32] bits of the lines before the band's first
+        if (lane < nb) baL[lane] = ba[lane];
+        wave_sync();
+        const int k0 = 16 * lane;
+        const uint4 bw = *reinterpret_cast<const uint4*>(S.bandOfLine + k0);
+        const unsigned bwv[4] = {bw.x, bw.y, bw.z, bw.w};
+        const int bandBefore = lane ? (int)S.bandOfLine[k0 - 1] : -1;
+        int v[16];
+        if (sizeof(MantT) == 2) {
+            const uint4 a0 = *reinterpret_cast<const uint4*>(m + k0), a1 = *reinterpret_cast<const uint4*>(m + k0 + 8);
+            const unsigned aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v[j] = (int)((aw[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int4 a = *reinterpret_cast<const int4*>(m + k0 + 4 * q);
+                v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+            }
+        }
+        unsigned bits[16];
+        int len[16], bandOf[16], run = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            bandOf[j] = (int)((bwv[j >> 2] >> (8 * (j & 3))) & 0xffu);
+            const int b = baL[bandOf[j]];
+            bits[j] = 0u; len[j] = 0;
+            if (b) code_of(sEmit, tbl, v[j], b, &bits[j], &len[j]);
+            run += len[j];
+        }
+        const int base = wave_scan_i(run) - run;
+        int at = base;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (bandOf[j] != (j ? bandOf[j - 1] : bandBefore)) bandPref[bandOf[j]] = at;   // this line starts its band
+            if (len[j]) put_bits(w, hdr + (bandOf[j] + 1) * hb + at, bits[j], len[j]);
+            at += len[j];
+        }
+        wave_sync();
+        if (lane < nb) {
+            const int b = baL[lane];
+            const unsigned hv = ((unsigned)(b ? b - 1 : 0) << P.nScaleBits) | ((unsigned)sf[lane] & scaleMask);
+            put_bits(w, hdr + lane * hb + bandPref[lane], hv & ((1u << hb) - 1u), hb);
+        }
+        wave_sync();
+        unsigned char* dstF = out + p0;
+        if (lane < 4) dstF[lane] = (unsigned char)(((unsigned)nBytes >> (8 * lane)) & 255u);
+        for (int j = lane; j < nBytes; j += kWave) dstF[4 + j] = (unsigned char)((w[j >> 2] >> (24 - 8 * (j & 3))) & 255u);
+        return;
     }
     // code length of every line -> LDS (coalesced over the lines), then an exclusive prefix sum: lane l scans the run
     // [l LPL, (l + 1) LPL) in place, the lane totals are scanned in registers
@@ -296,7 +386,8 @@ template <class MantT>
 static hipError_t launch_pack_t(const DevShape& S, const PackParams& P, const PackTables& T, int64_t nBlocks,
                                 const int* oscale, const int* msSwitch, const int* scaleFactor, const int* bitAlloc,
                                 const MantT* mant, const int* tableIn, int* tableOut, int* bitsSaved, unsigned char* out,
-                                long long outCap, long long* blockOffset, void* ws, int boundBytes, hipStream_t st) {
+                                long long outCap, long long* blockOffset, void* ws, int boundBytes, bool packFast16Ok,
+                                hipStream_t st) {
     const int64_t nChunks = nBlocks * P.nch;
     const int64_t nTiles = (nChunks + kScanTile - 1) / kScanTile;
     // workspace: pos [nChunks] | tile sums [nTiles] | total | error flag | chunkBytes [nChunks]
@@ -307,8 +398,10 @@ static hipError_t launch_pack_t(const DevShape& S, const PackParams& P, const Pa
     int* chunkBytes = errorFlag + 2;
     (void)hipMemsetAsync(errorFlag, 0, sizeof(int), st);
     const unsigned groups = (unsigned)((nChunks + kWavesPerGroup - 1) / kWavesPerGroup);
+    const int fast16 = S.halfN == 16 * kWave && S.nBands <= 32 && packFast16Ok &&
+                       !(reinterpret_cast<uintptr_t>(mant) & 15) && ((size_t)S.halfN * sizeof(MantT)) % 16 == 0;
     hipLaunchKernelGGL((pack_plan_kernel<MantT>), dim3(groups), dim3(kWave * kWavesPerGroup), 0, st, S, P, T, nChunks,
-                       bitAlloc, mant, tableIn, tableOut, bitsSaved, chunkBytes, errorFlag);
+                       bitAlloc, mant, tableIn, tableOut, bitsSaved, chunkBytes, errorFlag, fast16);
     hipLaunchKernelGGL(pack_scan_sums_kernel, dim3((unsigned)nTiles), dim3(256), 0, st, nChunks, chunkBytes, tileSum);
     hipLaunchKernelGGL(pack_scan_tiles_kernel, dim3(1), dim3(64), 0, st, (int)nTiles, tileSum, total);
     hipLaunchKernelGGL(pack_scan_apply_kernel, dim3((unsigned)nTiles), dim3(256), 0, st, nChunks, P.nch, chunkBytes,
@@ -317,20 +410,20 @@ static hipError_t launch_pack_t(const DevShape& S, const PackParams& P, const Pa
     const int prefLen = (S.halfN + (S.halfN >> 4)) + 2;
     const size_t lds = sizeof(unsigned) * (4 * (kPackLutSize + 1) + (size_t)kWavesPerGroup * (wordsPerWave + prefLen + kWave));
     hipLaunchKernelGGL((pack_write_kernel<MantT>), dim3(groups), dim3(kWave * kWavesPerGroup), lds, st, S, P, T, nChunks,
-                       oscale, msSwitch, scaleFactor, bitAlloc, mant, tableOut, chunkBytes, pos, out, outCap, wordsPerWave);
+                       oscale, msSwitch, scaleFactor, bitAlloc, mant, tableOut, chunkBytes, pos, out, outCap, wordsPerWave, fast16);
     return hipGetLastError();
 }
 
 hipError_t launch_pack(const DevShape& S, const PackParams& P, const PackTables& T, int64_t nBlocks, const int* oscale,
                        const int* msSwitch, const int* scaleFactor, const int* bitAlloc, const void* mant, int mantFmt,
                        const int* tableIn, int* tableOut, int* bitsSaved, unsigned char* out, long long outCap,
-                       long long* blockOffset, void* ws, int boundBytes, hipStream_t st) {
+                       long long* blockOffset, void* ws, int boundBytes, bool allBandsNonEmpty, hipStream_t st) {
     if (nBlocks <= 0) return hipSuccess;
     if (mantFmt == MRC_MANTISSA_I16)
         return launch_pack_t(S, P, T, nBlocks, oscale, msSwitch, scaleFactor, bitAlloc, (const unsigned short*)mant, tableIn,
-                             tableOut, bitsSaved, out, outCap, blockOffset, ws, boundBytes, st);
+                             tableOut, bitsSaved, out, outCap, blockOffset, ws, boundBytes, allBandsNonEmpty, st);
     return launch_pack_t(S, P, T, nBlocks, oscale, msSwitch, scaleFactor, bitAlloc, (const int*)mant, tableIn, tableOut,
-                         bitsSaved, out, outCap, blockOffset, ws, boundBytes, st);
+                         bitsSaved, out, outCap, blockOffset, ws, boundBytes, allBandsNonEmpty, st);
 }
 
 const int* pack_error_flag(const void* ws, int64_t nChunks) {
