@@ -149,7 +149,7 @@ def encode_stereo_streams(handle, streams, shapes, use_huffman=True, num_samples
     shapes[s] = block-shape sequence of stream s, num_samples[s] (optional) = the header's sample count.
     All streams advance one block per step on the GPU with their bit reservoirs chained on the device
     (batch.StreamEncoder.encode_chained: kernels + Huffman pricing, no host round trip per block); the
-    bytes are packed afterwards by the threaded C++ packer, one call per (step, block shape).  Returns a list
+    bytes are packed afterwards ON THE DEVICE too (mrc_dev_pack_blocks), one call per (step, block shape).  Returns a list
     of .pac byte strings, each identical to what encode_stereo_stream gives for that stream alone."""
     import torch
     from .batch import StreamEncoder
@@ -185,17 +185,17 @@ def encode_stereo_streams(handle, streams, shapes, use_huffman=True, num_samples
 
     parts = [[header(cfg, 2, sum(b for (_, _, b) in sh) if num_samples is None else num_samples[s])]
              for s, sh in enumerate(shapes)]
-    host = lambda o, k: o[k].cpu().numpy()
+    # the table of every chunk was chosen on the device (huffman_gain_kernel); recoding and bit packing happen there too
+    # (mrc_dev_pack_blocks): only the packed bytes and their offsets come back, the host cuts them per stream
+    def packed(a, b, out):
+        r = enc.pack(a, b, out, use_huffman=use_huffman, huff_table=out["huff_table"].contiguous())
+        return r["bytes"].cpu().numpy(), r["block_offset"].cpu().numpy()
     for ids, a, b, out in steps:
-        # the table of every chunk was chosen on the device (huffman_gain_kernel): the host only recodes and packs
-        data, offs, _, _ = pack_joint_blocks(cfg, a, b, host(out, "overall_scale"), host(out, "ms_switch"),
-                                             host(out, "scale_factor"), host(out, "bit_alloc"), host(out, "mantissa"),
-                                             huff_table=host(out, "huff_table"))
+        data, offs = packed(a, b, out)
         for i, s in enumerate(ids):
             parts[s].append(data[offs[i]:offs[i + 1]].tobytes())
     for out in closing:
-        data, offs, _, _ = pack_blocks(cfg, L, L, host(out, "overall_scale"), host(out, "scale_factor"),
-                                       host(out, "bit_alloc"), host(out, "mantissa"), huff_table=host(out, "huff_table"))
+        data, offs = packed(L, L, out)
         for s in range(nS):
             parts[s].append(data[offs[s]:offs[s + 1]].tobytes())
     return [b"".join(p) for p in parts]
