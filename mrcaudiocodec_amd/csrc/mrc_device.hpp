@@ -275,6 +275,24 @@ __device__ __forceinline__ double2* fft_lds_pow2(double2* A, double2* B, int n, 
     }
     return A;
 }
+// The 1024-point transform of the long block (five radix-4 passes) with every stride a compile-time constant: the index
+// splits, twiddle strides and quadrant fix-ups fold into immediates.  Same passes, same twiddles, same order as
+// fft_lds_pow2 -- bit-identical results.
+template <int NT = kThreads>
+__device__ __forceinline__ double2* fft_lds_1024(double2* A, double2* B, const double2* wq, int tid) {
+    const TwQuarter W{wq, 255, 8};
+    fft_pass<4, true, TwQuarter, NT>(A, B, 1024, 1, W, tid);
+    __syncthreads();
+    fft_pass<4, true, TwQuarter, NT>(B, A, 1024, 4, W, tid);
+    __syncthreads();
+    fft_pass<4, true, TwQuarter, NT>(A, B, 1024, 16, W, tid);
+    __syncthreads();
+    fft_pass<4, true, TwQuarter, NT>(B, A, 1024, 64, W, tid);
+    __syncthreads();
+    fft_pass<4, true, TwQuarter, NT>(A, B, 1024, 256, W, tid);
+    __syncthreads();
+    return B;
+}
 template <int NT = kThreads>
 __device__ __forceinline__ double2* fft_lds_global(double2* A, double2* B, int n, const int* rad, int nrad,
                                                    const double2* __restrict__ W, int tid) {

@@ -434,7 +434,9 @@ __device__ unsigned long long gPhaseCycles[16];
 #define MRC_PROFILE_SKIP 0                       // 1 far field, 2 direct pairs, 4 partial pairs, 8 chunk tail
 #endif
 
-template <bool EXACT, class SampleT, int NT>
+// LONG: the long block (N = 2048: H = M = 1024, 924 bins searched for peaks) with its dimensions as compile-time constants --
+// loop bounds, index splits and the LDS layout fold into immediates; same arithmetic, same results
+template <bool EXACT, class SampleT, int NT, bool LONG>
 __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsig, const SampleT* __restrict__ chL,
                                                        const SampleT* __restrict__ chR, int64_t stride,
                                                        const int64_t* __restrict__ offsets,
@@ -450,7 +452,8 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
     __shared__ unsigned char needBand[kMaxBands];       // joint blocks: does the encoder use THIS signal's SMR of the band?
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6;
-    const int H = S.H, M = S.halfN;
+    const int H = LONG ? 1024 : S.H, M = LONG ? 1024 : S.halfN;
+    const int last = LONG ? 924 : S.peakLast;           // bins 0 .. last-1 are inspected (psychoac.py:160)
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so hardware block
     // i + 1 runs on another die than block i.  Unit u below is chosen such that every XCD walks a CONTIGUOUS range of
     // (frame, signal) units: neighbouring frames share a hop, and the four signals of a joint frame share all their
@@ -473,10 +476,10 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
     double* xi = smem + 4 * H;                          // [peakLast + 1] intensity spectrum; later the suffix sums
     // region B is free once the spectrum is in xi: peak bins, then per-line masker counts (filled below)
     short* pkBin = reinterpret_cast<short*>(smem + 2 * H);              // [<= peakLast/2 + 1] peak bins, increasing
-    unsigned short* cntArr = reinterpret_cast<unsigned short*>(pkBin + ((S.peakLast / 2 + 5) & ~3));   // [M + 1]
+    unsigned short* cntArr = reinterpret_cast<unsigned short*>(pkBin + ((last / 2 + 5) & ~3));   // [M + 1]
     unsigned short* nUpArr = cntArr + (M + 2);                           // [M + 1]
     double* piHi = reinterpret_cast<double*>(nUpArr + (M + 2));          // [<= peakLast/2 + 2] prefix sums of the masker
-    double* piLo = piHi + (S.peakLast / 2 + 2);                          //   intensities, double-double (hi, lo)
+    double* piLo = piHi + (last / 2 + 2);                          //   intensities, double-double (hi, lo)
 
 #ifdef MRC_PROFILE_PHASES
     long long tPhase_ = clock64();
@@ -521,7 +524,6 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
             if (n < H) A[n] = make_double2(e[u] * he[u], o[u] * ho[u]);
         }
     }
-    const int last = S.peakLast;                        // bins 0 .. last-1 are inspected (psychoac.py:160)
     const double xiInv = 1.0 / S.xiDen;
     // Constants that are only needed after the FFT are requested BEFORE it (their LDS homes are FFT scratch until
     // then): the loads complete under the FFT's barriers instead of adding a memory round trip of their own.
@@ -542,6 +544,10 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
         for (int t = tid; t < H / 4; t += NT) Wq[t] = S.wH[t];
         __syncthreads();
         MRC_PHASE(0); MRC_STOP(0);
+#ifndef MRC_SMR_FFT8
+        if (LONG && NT == 256) T = fft_lds_1024<NT>(A, B, Wq, tid);
+        else
+#endif
         T = fft_lds_pow2<NT>(A, B, H, S.radH, S.nRadH, TwQuarter{Wq, H / 4 - 1, 31 - __clz(H / 4)}, tid);
     } else {
         __syncthreads();
@@ -1133,13 +1139,16 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
     const size_t lds = (size_t)total * sizeof(double);
     // blocks of up to 128 lines (two 64-line chunks) run as two-wave workgroups: no idle waves holding CU wave slots
     const dim3 grid((unsigned)(nFrames * nsig));
-#define MRC_SMR_LAUNCH(EX, TY, THREADS)                                                                              \
-    hipLaunchKernelGGL((smr_kernel<EX, TY, THREADS>), grid, dim3(THREADS), lds, st, S, nsig, (const TY*)chL,         \
+#define MRC_SMR_LAUNCH(EX, TY, THREADS, LG)                                                                          \
+    hipLaunchKernelGGL((smr_kernel<EX, TY, THREADS, LG>), grid, dim3(THREADS), lds, st, S, nsig, (const TY*)chL,     \
                        (const TY*)chR, stride, offsets, lines, oscale, smr, thresh, bandPeak, msSwitch, lay)
 #ifndef MRC_SMR_THREADS                          // workgroup size for blocks of more than 128 lines
 #define MRC_SMR_THREADS 256
 #endif
-#define MRC_SMR_PICK(EX, TY) do { if (M <= 2 * kWave) MRC_SMR_LAUNCH(EX, TY, 128); else MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS); } while (0)
+    const bool isLong = H == 1024 && M == 1024 && S.peakLast == 924 && MRC_SMR_THREADS == 256;
+#define MRC_SMR_PICK(EX, TY) do { if (M <= 2 * kWave) MRC_SMR_LAUNCH(EX, TY, 128, false);                            \
+                                  else if (isLong && !EX) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, true);             \
+                                  else MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, false); } while (0)
     if (fmt == kSampleI16) { if (exactSpread) MRC_SMR_PICK(true, short); else MRC_SMR_PICK(false, short); }
     else { if (exactSpread) MRC_SMR_PICK(true, double); else MRC_SMR_PICK(false, double); }
 #undef MRC_SMR_PICK
