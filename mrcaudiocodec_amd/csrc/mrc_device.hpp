@@ -293,6 +293,20 @@ __device__ __forceinline__ double2* fft_lds_1024(double2* A, double2* B, const d
     __syncthreads();
     return B;
 }
+// ... and the 128-point transform of the short block (4 x 4 x 4 x 2)
+template <int NT = kThreads>
+__device__ __forceinline__ double2* fft_lds_128(double2* A, double2* B, const double2* wq, int tid) {
+    const TwQuarter W{wq, 31, 5};
+    fft_pass<4, true, TwQuarter, NT>(A, B, 128, 1, W, tid);
+    __syncthreads();
+    fft_pass<4, true, TwQuarter, NT>(B, A, 128, 4, W, tid);
+    __syncthreads();
+    fft_pass<4, true, TwQuarter, NT>(A, B, 128, 16, W, tid);
+    __syncthreads();
+    fft_pass<2, true, TwQuarter, NT>(B, A, 128, 64, W, tid);
+    __syncthreads();
+    return A;
+}
 template <int NT = kThreads>
 __device__ __forceinline__ double2* fft_lds_global(double2* A, double2* B, int n, const int* rad, int nrad,
                                                    const double2* __restrict__ W, int tid) {

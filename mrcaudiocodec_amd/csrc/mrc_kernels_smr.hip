@@ -434,9 +434,10 @@ __device__ unsigned long long gPhaseCycles[16];
 #define MRC_PROFILE_SKIP 0                       // 1 far field, 2 direct pairs, 4 partial pairs, 8 chunk tail
 #endif
 
-// LONG: the long block (N = 2048: H = M = 1024, 924 bins searched for peaks) with its dimensions as compile-time constants --
-// loop bounds, index splits and the LDS layout fold into immediates; same arithmetic, same results
-template <bool EXACT, class SampleT, int NT, bool LONG>
+// DIM: 1024 = the long block (N = 2048: H = M = 1024, 924 bins searched for peaks), 128 = the short block (N = 256: H = M =
+// 128, 28 bins) with their dimensions as compile-time constants -- loop bounds, index splits and the LDS layout fold into
+// immediates; same arithmetic, same results.  0: any shape, dimensions from DevShape.
+template <bool EXACT, class SampleT, int NT, int DIM>
 __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsig, const SampleT* __restrict__ chL,
                                                        const SampleT* __restrict__ chR, int64_t stride,
                                                        const int64_t* __restrict__ offsets,
@@ -452,8 +453,9 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
     __shared__ unsigned char needBand[kMaxBands];       // joint blocks: does the encoder use THIS signal's SMR of the band?
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6;
-    const int H = LONG ? 1024 : S.H, M = LONG ? 1024 : S.halfN;
-    const int last = LONG ? 924 : S.peakLast;           // bins 0 .. last-1 are inspected (psychoac.py:160)
+    constexpr bool LONG = DIM == 1024;
+    const int H = DIM ? DIM : S.H, M = DIM ? DIM : S.halfN;
+    const int last = DIM ? DIM - 100 : S.peakLast;      // bins 0 .. last-1 are inspected (psychoac.py:160)
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so hardware block
     // i + 1 runs on another die than block i.  Unit u below is chosen such that every XCD walks a CONTIGUOUS range of
     // (frame, signal) units: neighbouring frames share a hop, and the four signals of a joint frame share all their
@@ -546,6 +548,7 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
         MRC_PHASE(0); MRC_STOP(0);
 #ifndef MRC_SMR_FFT8
         if (LONG && NT == 256) T = fft_lds_1024<NT>(A, B, Wq, tid);
+        else if (DIM == 128) T = fft_lds_128<NT>(A, B, Wq, tid);
         else
 #endif
         T = fft_lds_pow2<NT>(A, B, H, S.radH, S.nRadH, TwQuarter{Wq, H / 4 - 1, 31 - __clz(H / 4)}, tid);
@@ -1145,10 +1148,12 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
 #ifndef MRC_SMR_THREADS                          // workgroup size for blocks of more than 128 lines
 #define MRC_SMR_THREADS 256
 #endif
-    const bool isLong = H == 1024 && M == 1024 && S.peakLast == 924 && MRC_SMR_THREADS == 256;
-#define MRC_SMR_PICK(EX, TY) do { if (M <= 2 * kWave) MRC_SMR_LAUNCH(EX, TY, 128, false);                            \
-                                  else if (isLong && !EX) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, true);             \
-                                  else MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, false); } while (0)
+    const bool isLong = H == 1024 && M == 1024 && S.peakLast == 924 && MRC_SMR_THREADS == 256 && lay.twOff >= 0;
+    const bool isShort = H == 128 && M == 128 && S.peakLast == 28 && lay.twOff >= 0;
+#define MRC_SMR_PICK(EX, TY) do { if (isShort && !EX) MRC_SMR_LAUNCH(EX, TY, 128, 128);                               \
+                                  else if (M <= 2 * kWave) MRC_SMR_LAUNCH(EX, TY, 128, 0);                           \
+                                  else if (isLong && !EX) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 1024);             \
+                                  else MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 0); } while (0)
     if (fmt == kSampleI16) { if (exactSpread) MRC_SMR_PICK(true, short); else MRC_SMR_PICK(false, short); }
     else { if (exactSpread) MRC_SMR_PICK(true, double); else MRC_SMR_PICK(false, double); }
 #undef MRC_SMR_PICK
