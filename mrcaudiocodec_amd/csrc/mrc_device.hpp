@@ -307,6 +307,22 @@ __device__ __forceinline__ double2* fft_lds_128(double2* A, double2* B, const do
     __syncthreads();
     return A;
 }
+// ... and the 576-point transform of the transition blocks (4 x 4 x 4 x 3 x 3, twiddles from global memory)
+template <int NT = kThreads>
+__device__ __forceinline__ double2* fft_lds_576(double2* A, double2* B, const double2* __restrict__ w, int tid) {
+    const TwGlobal W{w};
+    fft_pass<4, true, TwGlobal, NT>(A, B, 576, 1, W, tid);
+    __syncthreads();
+    fft_pass<4, true, TwGlobal, NT>(B, A, 576, 4, W, tid);
+    __syncthreads();
+    fft_pass<4, true, TwGlobal, NT>(A, B, 576, 16, W, tid);
+    __syncthreads();
+    fft_pass<3, true, TwGlobal, NT>(B, A, 576, 64, W, tid);
+    __syncthreads();
+    fft_pass<3, false, TwGlobal, NT>(A, B, 576, 192, W, tid);
+    __syncthreads();
+    return B;
+}
 template <int NT = kThreads>
 __device__ __forceinline__ double2* fft_lds_global(double2* A, double2* B, int n, const int* rad, int nrad,
                                                    const double2* __restrict__ W, int tid) {

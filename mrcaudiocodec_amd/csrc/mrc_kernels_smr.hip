@@ -435,7 +435,7 @@ __device__ unsigned long long gPhaseCycles[16];
 #endif
 
 // DIM: 1024 = the long block (N = 2048: H = M = 1024, 924 bins searched for peaks), 128 = the short block (N = 256: H = M =
-// 128, 28 bins) with their dimensions as compile-time constants -- loop bounds, index splits and the LDS layout fold into
+// 128, 28 bins), 576 = the transition blocks (N = 1152) with their dimensions as compile-time constants -- loop bounds, index splits and the LDS layout fold into
 // immediates; same arithmetic, same results.  0: any shape, dimensions from DevShape.
 template <bool EXACT, class SampleT, int NT, int DIM>
 __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsig, const SampleT* __restrict__ chL,
@@ -555,6 +555,10 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
     } else {
         __syncthreads();
         MRC_PHASE(0); MRC_STOP(0);
+#ifndef MRC_SMR_FFT8
+        if (DIM == 576) T = fft_lds_576<NT>(A, B, S.wH, tid);
+        else
+#endif
         T = fft_lds_global<NT>(A, B, H, S.radH, S.nRadH, S.wH, tid);
     }
     MRC_PHASE(1); MRC_STOP(1);
@@ -1150,9 +1154,11 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
 #endif
     const bool isLong = H == 1024 && M == 1024 && S.peakLast == 924 && MRC_SMR_THREADS == 256 && lay.twOff >= 0;
     const bool isShort = H == 128 && M == 128 && S.peakLast == 28 && lay.twOff >= 0;
+    const bool isTrans = H == 576 && M == 576 && S.peakLast == 476 && lay.twOff < 0 && MRC_SMR_THREADS == 256;
 #define MRC_SMR_PICK(EX, TY) do { if (isShort && !EX) MRC_SMR_LAUNCH(EX, TY, 128, 128);                               \
                                   else if (M <= 2 * kWave) MRC_SMR_LAUNCH(EX, TY, 128, 0);                           \
                                   else if (isLong && !EX) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 1024);             \
+                                  else if (isTrans && !EX) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 576);             \
                                   else MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 0); } while (0)
     if (fmt == kSampleI16) { if (exactSpread) MRC_SMR_PICK(true, short); else MRC_SMR_PICK(false, short); }
     else { if (exactSpread) MRC_SMR_PICK(true, double); else MRC_SMR_PICK(false, double); }
