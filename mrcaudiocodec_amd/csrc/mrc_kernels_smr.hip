@@ -437,13 +437,15 @@ __device__ unsigned long long gPhaseCycles[16];
 // DIM: 1024 = the long block (N = 2048: H = M = 1024, 924 bins searched for peaks), 128 = the short block (N = 256: H = M =
 // 128, 28 bins), 576 = the transition blocks (N = 1152) with their dimensions as compile-time constants -- loop bounds, index splits and the LDS layout fold into
 // immediates; same arithmetic, same results.  0: any shape, dimensions from DevShape.
-template <bool EXACT, class SampleT, int NT, int DIM>
-__global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsig, const SampleT* __restrict__ chL,
+// MODE: what the hot paths fix at compile time -- 1: mono (one signal per frame, every band wanted, no thresholds out, band
+// peaks out, strided frames); 2: joint stereo with the M/S switch known (four signals, the rest alike); 0: all of it at run time.
+template <bool EXACT, class SampleT, int NT, int DIM, int MODE>
+__global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsigArg, const SampleT* __restrict__ chL,
                                                        const SampleT* __restrict__ chR, int64_t stride,
-                                                       const int64_t* __restrict__ offsets,
+                                                       const int64_t* __restrict__ offsetsArg,
                                                        const double* __restrict__ lines,
                                                        const int* __restrict__ oscale, double* __restrict__ smr,
-                                                       double* __restrict__ thresh, double* __restrict__ bandPeak,
+                                                       double* __restrict__ threshArg, double* __restrict__ bandPeakArg,
                                                        const int* __restrict__ msSwitch, SmrLds lay) {
     extern __shared__ double smem[];
     __shared__ int waveCnt[NT / kWave];
@@ -454,6 +456,12 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6;
     constexpr bool LONG = DIM == 1024;
+    const int nsig = MODE == 1 ? 1 : MODE == 2 ? 4 : nsigArg;
+    const bool haveSwitch = MODE == 1 ? false : MODE == 2 ? true : msSwitch != nullptr;
+    const int64_t* offsets = MODE ? nullptr : offsetsArg;
+    double* thresh = MODE ? nullptr : threshArg;
+    double* bandPeak = bandPeakArg;
+    const bool wantPeak = MODE ? true : bandPeakArg != nullptr;
     const int H = DIM ? DIM : S.H, M = DIM ? DIM : S.halfN;
     const int last = DIM ? DIM - 100 : S.peakLast;      // bins 0 .. last-1 are inspected (psychoac.py:160)
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so hardware block
@@ -497,7 +505,7 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
     // never reach the bit allocation.  With the switch known (it only needs the MDCT lines) the sweep below leaves out
     // the 64-line chunks none of whose bands want this signal -- half of all (signal, band) pairs of a stereo frame.
     if (tid < kMaxBands)
-        needBand[tid] = (!msSwitch || tid >= S.nBands) ? 1 : (((sig >= 2) == (msSwitch[f * S.nBands + tid] != 0)) ? 1 : 0);
+        needBand[tid] = (!haveSwitch || tid >= S.nBands) ? 1 : (((sig >= 2) == (msSwitch[f * S.nBands + tid] != 0)) ? 1 : 0);
     const double* zbS = smem + lay.zbOff;               // staged after the FFT (the area is FFT scratch / dead)
     const double* e2tab = smem + 2 * H - kExpTab;       // 2^(j/64): the tail of region A, behind the masker table
     // per-band max of (line intensity / masked threshold) as the bit pattern of a positive double; in front of e2tab
@@ -722,7 +730,7 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
                     double xs = ldexp(X[k], scale);                              // codecThem.py:323 (exact)
                     double spl = spl_db(2. * (xs * xs) / (1. / 2.)) - 6. * scale;   // psychoac.py:212
                     atomicMax(&bandKey[S.bandOfLine[k]], order_key(spl - thr));
-                    if (bandPeak)
+                    if (wantPeak)
                         atomicMax(&peakKey[S.bandOfLine[k]], (unsigned long long)__double_as_longlong(fabs(X[k])));
                 }
             }
@@ -866,7 +874,7 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
             // maskers more than 1/2 Bark below every line of chunk c -- 0: the chunk takes no far field
             auto far_count = [&](int c) -> int {
                 const int kc = min(c * kWave + lane, M - 1);
-                if (!__any(needBand[S.bandOfLine[kc]])) return 0;                  // (see needBand)
+                if (haveSwitch && !__any(needBand[S.bandOfLine[kc]])) return 0;                  // (see needBand)
                 const int nf = __builtin_amdgcn_readfirstlane((int)nUpArr[kc]);    // nUp of the chunk's first line
                 return (nf < kFarMinMaskers || (MRC_PROFILE_SKIP & 1)) ? 0 : nf;
             };
@@ -936,7 +944,7 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
             const int c = chunk_of(i0 + u);
             if (c >= nChunks) break;
             const int kc = min(c * kWave + lane, M - 1);
-            if (!__any(needBand[S.bandOfLine[kc]])) continue;                      // (see needBand)
+            if (haveSwitch && !__any(needBand[S.bandOfLine[kc]])) continue;                      // (see needBand)
             const int nFar = __builtin_amdgcn_readfirstlane((int)nUpArr[kc]);      // nUp of the chunk's first line
             if (nFar < kFarMinMaskers || (MRC_PROFILE_SKIP & 1)) continue;
             const double z = S.zb[kc];
@@ -992,7 +1000,7 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
             const int kc = min(k, M - 1);
             const LineConst cur = nxt;
             nxt = load_consts(i + 1);
-            if (!__any(needBand[cur.bnd])) continue;                               // (see needBand)
+            if (haveSwitch && !__any(needBand[cur.bnd])) continue;                               // (see needBand)
             const double z = cur.z;
             // quiet threshold + far field (psychoac.py:155,166-168; the order of the additions is free, see above)
             double tot = cur.quiet + (u == 0 ? far0 : u == 1 ? far1 : u == 2 ? far2 : far3);
@@ -1069,14 +1077,14 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
                     const double best = wave_max(ex);
                     if (lane == 0) atomicMax(&bandKey[bnd], order_key(best));
                 }
-                if (bandPeak) {
+                if (wantPeak) {
                     const double pk = wave_max(fabs(cur.x));
                     if (lane == 0) atomicMax(&peakKey[bnd], (unsigned long long)__double_as_longlong(pk));
                 }
             } else {
                 atomicMax(&ratioKey[bnd], (unsigned long long)__double_as_longlong(q));
                 if (plain) atomicMax(&bandKey[bnd], order_key(ex));
-                if (bandPeak) atomicMax(&peakKey[bnd], (unsigned long long)__double_as_longlong(fabs(cur.x)));
+                if (wantPeak) atomicMax(&peakKey[bnd], (unsigned long long)__double_as_longlong(fabs(cur.x)));
             }
             MRC_PHASE(10);
         }
@@ -1093,7 +1101,7 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
         smr[(int64_t)unit * S.nBands + bnd] = v;
         // max |X| per band of the UNSCALED lines: what the scale factors need (codecThem.py:346), so the back end
         // does not have to read the lines once more for it
-        if (bandPeak) bandPeak[(int64_t)unit * S.nBands + bnd] = __longlong_as_double((long long)peakKey[bnd]);
+        if (wantPeak) bandPeak[(int64_t)unit * S.nBands + bnd] = __longlong_as_double((long long)peakKey[bnd]);
     }
 }
 
@@ -1146,8 +1154,8 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
     const size_t lds = (size_t)total * sizeof(double);
     // blocks of up to 128 lines (two 64-line chunks) run as two-wave workgroups: no idle waves holding CU wave slots
     const dim3 grid((unsigned)(nFrames * nsig));
-#define MRC_SMR_LAUNCH(EX, TY, THREADS, LG)                                                                          \
-    hipLaunchKernelGGL((smr_kernel<EX, TY, THREADS, LG>), grid, dim3(THREADS), lds, st, S, nsig, (const TY*)chL,     \
+#define MRC_SMR_LAUNCH(EX, TY, THREADS, LG, MD)                                                                      \
+    hipLaunchKernelGGL((smr_kernel<EX, TY, THREADS, LG, MD>), grid, dim3(THREADS), lds, st, S, nsig, (const TY*)chL, \
                        (const TY*)chR, stride, offsets, lines, oscale, smr, thresh, bandPeak, msSwitch, lay)
 #ifndef MRC_SMR_THREADS                          // workgroup size for blocks of more than 128 lines
 #define MRC_SMR_THREADS 256
@@ -1155,11 +1163,15 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
     const bool isLong = H == 1024 && M == 1024 && S.peakLast == 924 && MRC_SMR_THREADS == 256 && lay.twOff >= 0;
     const bool isShort = H == 128 && M == 128 && S.peakLast == 28 && lay.twOff >= 0;
     const bool isTrans = H == 576 && M == 576 && S.peakLast == 476 && lay.twOff < 0 && MRC_SMR_THREADS == 256;
-#define MRC_SMR_PICK(EX, TY) do { if (isShort && !EX) MRC_SMR_LAUNCH(EX, TY, 128, 128);                               \
-                                  else if (M <= 2 * kWave) MRC_SMR_LAUNCH(EX, TY, 128, 0);                           \
-                                  else if (isLong && !EX) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 1024);             \
-                                  else if (isTrans && !EX) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 576);             \
-                                  else MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 0); } while (0)
+    // the hot paths of the long block: mono, and joint stereo with the switch known (no thresholds wanted, strided frames)
+    const int mode = (thresh || offsets || !bandPeak) ? 0 : (nsig == 1 && !msSwitch) ? 1 : (nsig == 4 && msSwitch) ? 2 : 0;
+#define MRC_SMR_PICK(EX, TY) do { if (isShort && !EX) MRC_SMR_LAUNCH(EX, TY, 128, 128, 0);                            \
+                                  else if (M <= 2 * kWave) MRC_SMR_LAUNCH(EX, TY, 128, 0, 0);                        \
+                                  else if (isLong && !EX && mode == 1) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 1024, 1);   \
+                                  else if (isLong && !EX && mode == 2) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 1024, 2);   \
+                                  else if (isLong && !EX) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 1024, 0);          \
+                                  else if (isTrans && !EX) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 576, 0);          \
+                                  else MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 0, 0); } while (0)
     if (fmt == kSampleI16) { if (exactSpread) MRC_SMR_PICK(true, short); else MRC_SMR_PICK(false, short); }
     else { if (exactSpread) MRC_SMR_PICK(true, double); else MRC_SMR_PICK(false, double); }
 #undef MRC_SMR_PICK
