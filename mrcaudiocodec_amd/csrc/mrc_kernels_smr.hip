@@ -438,7 +438,7 @@ __device__ unsigned long long gPhaseCycles[16];
 // 128, 28 bins), 576 = the transition blocks (N = 1152) with their dimensions as compile-time constants -- loop bounds, index splits and the LDS layout fold into
 // immediates; same arithmetic, same results.  0: any shape, dimensions from DevShape.
 // MODE: what the hot paths fix at compile time -- 1: mono (one signal per frame, every band wanted, no thresholds out, band
-// peaks out, strided frames); 2: joint stereo with the M/S switch known (four signals, the rest alike); 0: all of it at run time.
+// peaks out); 2: joint stereo with the M/S switch known (four signals, the rest alike); 0: all of it at run time.
 template <bool EXACT, class SampleT, int NT, int DIM, int MODE>
 __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsigArg, const SampleT* __restrict__ chL,
                                                        const SampleT* __restrict__ chR, int64_t stride,
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
     constexpr bool LONG = DIM == 1024;
     const int nsig = MODE == 1 ? 1 : MODE == 2 ? 4 : nsigArg;
     const bool haveSwitch = MODE == 1 ? false : MODE == 2 ? true : msSwitch != nullptr;
-    const int64_t* offsets = MODE ? nullptr : offsetsArg;
+    const int64_t* offsets = offsetsArg;                 // (strided frames or explicit block offsets: one select per unit either way)
     double* thresh = MODE ? nullptr : threshArg;
     double* bandPeak = bandPeakArg;
     const bool wantPeak = MODE ? true : bandPeakArg != nullptr;
@@ -1163,13 +1163,15 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
     const bool isLong = H == 1024 && M == 1024 && S.peakLast == 924 && MRC_SMR_THREADS == 256 && lay.twOff >= 0;
     const bool isShort = H == 128 && M == 128 && S.peakLast == 28 && lay.twOff >= 0;
     const bool isTrans = H == 576 && M == 576 && S.peakLast == 476 && lay.twOff < 0 && MRC_SMR_THREADS == 256;
-    // the hot paths of the long block: mono, and joint stereo with the switch known (no thresholds wanted, strided frames)
-    const int mode = (thresh || offsets || !bandPeak) ? 0 : (nsig == 1 && !msSwitch) ? 1 : (nsig == 4 && msSwitch) ? 2 : 0;
-#define MRC_SMR_PICK(EX, TY) do { if (isShort && !EX) MRC_SMR_LAUNCH(EX, TY, 128, 128, 0);                            \
+    // the hot paths: mono, and (long blocks) joint stereo with the switch known; no thresholds wanted
+    const int mode = (thresh || !bandPeak) ? 0 : (nsig == 1 && !msSwitch) ? 1 : (nsig == 4 && msSwitch) ? 2 : 0;
+#define MRC_SMR_PICK(EX, TY) do { if (isShort && !EX && mode == 1) MRC_SMR_LAUNCH(EX, TY, 128, 128, 1);               \
+                                  else if (isShort && !EX) MRC_SMR_LAUNCH(EX, TY, 128, 128, 0);                      \
                                   else if (M <= 2 * kWave) MRC_SMR_LAUNCH(EX, TY, 128, 0, 0);                        \
                                   else if (isLong && !EX && mode == 1) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 1024, 1);   \
                                   else if (isLong && !EX && mode == 2) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 1024, 2);   \
                                   else if (isLong && !EX) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 1024, 0);          \
+                                  else if (isTrans && !EX && mode == 1) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 576, 1);   \
                                   else if (isTrans && !EX) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 576, 0);          \
                                   else MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 0, 0); } while (0)
     if (fmt == kSampleI16) { if (exactSpread) MRC_SMR_PICK(true, short); else MRC_SMR_PICK(false, short); }
