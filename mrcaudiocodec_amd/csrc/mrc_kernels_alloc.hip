@@ -197,8 +197,10 @@ __global__ __launch_bounds__(kWave) void bitalloc_cases_kernel(int64_t nCases, i
 // ------------------------------------------------------------------------------------------------
 // scale factors + mantissas: one wavefront per (frame, stream)
 // ------------------------------------------------------------------------------------------------
-template <class OutT>                                  // int32 plane, or uint16 (codes are at most 16 bits wide: codecThem.py:292-293)
-__global__ __launch_bounds__(kWave) void quantize_kernel(DevShape S, int joint, const double* __restrict__ lines,
+// LONGJ: -1 any shape, joint or not at run time; 0 / 1: the long block (1024 lines), independent / joint channels fixed at
+// compile time (the four iterations of the line loop unroll, the stream arithmetic folds)
+template <class OutT, int LONGJ>                       // int32 plane, or uint16 (codes are at most 16 bits wide: codecThem.py:292-293)
+__global__ __launch_bounds__(kWave) void quantize_kernel(DevShape S, int jointArg, const double* __restrict__ lines,
                                                          const int* __restrict__ oscale,
                                                          const double* __restrict__ bandPeak,
                                                          const int* __restrict__ msSwitch,
@@ -208,10 +210,11 @@ __global__ __launch_bounds__(kWave) void quantize_kernel(DevShape S, int joint, 
     __shared__ unsigned int sInfo[kMaxBands];            // per band: bits | scale factor << 8 | overall scale << 16 | signal << 24
     __shared__ __attribute__((aligned(4))) unsigned char sBand[kBandLds];   // band of every line (copy of S.bandOfLine)
     const int lane = threadIdx.x;
+    const int joint = LONGJ < 0 ? jointArg : LONGJ;
     const int nstream = joint ? 2 : 1, nsig = joint ? 4 : 1;
     const int64_t f = blockIdx.x / nstream;
     const int strm = blockIdx.x % nstream;
-    const int M = S.halfN, nb = S.nBands;
+    const int M = LONGJ < 0 ? S.halfN : 1024, nb = S.nBands;
     const double* X = lines + f * nsig * M;
     const int* osc = oscale + f * nsig;
     // the line -> band map goes to LDS with the other per-band values: the loop below then has ONE global round
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(kWave) void quantize_kernel(DevShape S, int joint, 
         const int ba = (int)(info & 0xff);
         return (OutT)(ba ? mantissa_dev(ldexp(x, (int)((info >> 16) & 0xff)), (int)((info >> 8) & 0xff), S.nScaleBits, ba) : 0);
     };
-    if (vecOk && bandInLds && !(M & 3)) {
+    if ((LONGJ >= 0 || vecOk) && bandInLds && !(M & 3)) {       // (LONGJ: the launcher has checked the alignment)
         // a lane takes FOUR CONSECUTIVE lines: one LDS word for their bands, 32 contiguous bytes of lines (one signal: the
         // four lines of a lane lie in one band almost always), one 8- or 16-byte store of the four codes
         for (int k = 4 * lane; k < M; k += 4 * kWave) {
@@ -320,12 +323,17 @@ hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, con
                        nFrames, fpw, smr, msSwitch, resIn, bitAlloc, resOut);
     if (ev) (void)hipEventRecord(ev[1], st);
     const int vecOk = !((reinterpret_cast<uintptr_t>(lines) | reinterpret_cast<uintptr_t>(mantissa)) & 15);
-    if (mantFmt == MRC_MANTISSA_I16)
-        hipLaunchKernelGGL(quantize_kernel<unsigned short>, dim3((unsigned)(nFrames * (joint ? 2 : 1))), dim3(kWave), 0, st, S, joint,
-                           lines, oscale, bandPeakWs, msSwitch, bitAlloc, scaleFactor, (unsigned short*)mantissa, vecOk);
-    else
-        hipLaunchKernelGGL(quantize_kernel<int>, dim3((unsigned)(nFrames * (joint ? 2 : 1))), dim3(kWave), 0, st, S, joint,
-                           lines, oscale, bandPeakWs, msSwitch, bitAlloc, scaleFactor, (int*)mantissa, vecOk);
+    const dim3 qgrid((unsigned)(nFrames * (joint ? 2 : 1)));
+    const int longj = (S.halfN == 1024 && vecOk) ? (joint ? 1 : 0) : -1;
+#define MRC_Q_LAUNCH(TY, LJ)                                                                                         \
+    hipLaunchKernelGGL((quantize_kernel<TY, LJ>), qgrid, dim3(kWave), 0, st, S, joint, lines, oscale, bandPeakWs,    \
+                       msSwitch, bitAlloc, scaleFactor, (TY*)mantissa, vecOk)
+#define MRC_Q_PICK(TY) do { if (longj == 0) MRC_Q_LAUNCH(TY, 0); else if (longj == 1) MRC_Q_LAUNCH(TY, 1);            \
+                            else MRC_Q_LAUNCH(TY, -1); } while (0)
+    if (mantFmt == MRC_MANTISSA_I16) MRC_Q_PICK(unsigned short);
+    else MRC_Q_PICK(int);
+#undef MRC_Q_PICK
+#undef MRC_Q_LAUNCH
     return hipGetLastError();
 }
 

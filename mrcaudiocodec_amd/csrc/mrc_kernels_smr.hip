@@ -369,6 +369,31 @@ __device__ __attribute__((noinline)) double excess_plain(double t, double a2, in
 // Where the staged tables sit in the dynamic LDS (offsets in doubles, chosen by launch_smr): the Bark grid of the
 // lines for the masker-side searches, the log10 table, the first quadrant of the FFT twiddles (-1: use global).
 struct SmrLds { int zbOff, logOff, twOff; };
+// The layout for a block of H FFT points, M lines and `last` searched bins; *total = doubles of dynamic LDS.  One function
+// for the launcher (any shape) and, evaluated at compile time, for the kernels specialised on the block dimensions.
+__host__ __device__ constexpr SmrLds smr_layout(int H, int M, int last, int* totalOut) {
+    int total = 4 * H + last + 1;
+    const int pkShorts = (last / 2 + 5) & ~3;
+    const int piOff = 2 * H + (pkShorts * 2 + 2 * (M + 2) * 2) / 8;          // where piHi starts (kernel layout)
+    const int piLen = 2 * (last / 2 + 2);
+    const int logLen = kLogTabEntries * 4;
+    SmrLds lay{0, 0, -1};
+    if (piOff + (piLen > M ? piLen : M) + logLen <= 4 * H) {
+        lay.zbOff = piOff;                               // overwritten by the prefix sums after the searches
+        lay.logOff = 4 * H - logLen;
+    } else {
+        total += total & 1;
+        lay.zbOff = total;
+        lay.logOff = total + M;
+        total += M + logLen;
+    }
+    if ((H & (H - 1)) == 0 && H >= 16) {                 // first quadrant of the FFT twiddles: in the spectrum area
+        if (H / 2 <= last + 1) lay.twOff = 4 * H;
+        else { total += total & 1; lay.twOff = total; total += H / 2; }
+    }
+    if (totalOut) *totalOut = total;
+    return lay;
+}
 
 // inclusive prefix sum over the 64 lanes, in registers: Kogge-Stone inside each 16-lane row with DPP row shifts (lanes
 // that would read across the row's start get 0), then the row totals are passed on with row_bcast:15 / row_bcast:31
@@ -446,8 +471,9 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
                                                        const double* __restrict__ lines,
                                                        const int* __restrict__ oscale, double* __restrict__ smr,
                                                        double* __restrict__ threshArg, double* __restrict__ bandPeakArg,
-                                                       const int* __restrict__ msSwitch, SmrLds lay) {
+                                                       const int* __restrict__ msSwitch, SmrLds layArg) {
     extern __shared__ double smem[];
+    const SmrLds lay = DIM ? smr_layout(DIM, DIM, DIM - 100, nullptr) : layArg;
     __shared__ int waveCnt[NT / kWave];
     __shared__ unsigned long long bandKey[kMaxBands];   // per-band running max of the excess (order-preserving key)
     __shared__ unsigned long long slopeKey[2];          // min / max upper slope over the frame's maskers (keys)
@@ -1128,26 +1154,8 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
     // areas that are dead when they are needed if there is room (the long block is sized for 4 workgroups per CU
     // and must not grow), else behind the spectrum.
     const int H = S.H, M = S.halfN;
-    int total = 4 * H + S.peakLast + 1;
-    const int pkShorts = (S.peakLast / 2 + 5) & ~3;
-    const int piOff = 2 * H + (pkShorts * 2 + 2 * (M + 2) * 2) / 8;          // where piHi starts (kernel layout)
-    const int piLen = 2 * (S.peakLast / 2 + 2);
-    const int logLen = kLogTabEntries * 4;
-    SmrLds lay;
-    if (piOff + std::max(piLen, M) + logLen <= 4 * H) {
-        lay.zbOff = piOff;                               // overwritten by the prefix sums after the searches
-        lay.logOff = 4 * H - logLen;
-    } else {
-        total += total & 1;
-        lay.zbOff = total;
-        lay.logOff = total + M;
-        total += M + logLen;
-    }
-    lay.twOff = -1;
-    if ((H & (H - 1)) == 0 && H >= 16) {                 // first quadrant of the FFT twiddles: in the spectrum area
-        if (H / 2 <= S.peakLast + 1) lay.twOff = 4 * H;
-        else { total += total & 1; lay.twOff = total; total += H / 2; }
-    }
+    int total = 0;
+    const SmrLds lay = smr_layout(H, M, S.peakLast, &total);
 #ifdef MRC_PROFILE_EXTRA_LDS                     // profiling aid: pad the workgroup's LDS (occupancy experiments)
     total += MRC_PROFILE_EXTRA_LDS / 8;
 #endif
