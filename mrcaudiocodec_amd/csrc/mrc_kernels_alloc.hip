@@ -58,7 +58,7 @@ struct AllocSlabs {
     int* nLines;            // [nTot]
     int gs, nG;
 };
-__host__ __device__ inline int alloc_group_size(int nTot) { return nTot <= 16 ? 4 : nTot <= 32 ? 6 : 8; }
+__host__ __device__ constexpr int alloc_group_size(int nTot) { return nTot <= 16 ? 4 : nTot <= 32 ? 6 : 8; }
 __host__ __device__ inline size_t alloc_lds_bytes(int nTot, int ld) {
     const int gs = alloc_group_size(nTot), nG = (nTot + gs - 1) / gs;
     return (size_t)(nTot + nG) * ld * sizeof(double) + (((size_t)(nTot + nG) * ld + 3) & ~(size_t)3) + (size_t)nTot * sizeof(int);
@@ -75,20 +75,40 @@ __device__ __forceinline__ AllocSlabs alloc_slabs(double* lds, int nTot, int ld)
     return a;
 }
 
-__device__ __forceinline__ void alloc_rescan(const AllocSlabs& A, int G, int nTot, int lane, int ld) {
-    const int b0 = G * A.gs, b1 = min(b0 + A.gs, nTot);
+// NTOT > 0: the number of bands (x streams) as a compile-time constant -- group size, group count and the row stride (64
+// lanes) fold, the scans over a group and over the group maxima unroll (their LDS reads go out together instead of one
+// per loop trip); 0: taken from the arguments.
+template <int NTOT>
+__device__ __forceinline__ void alloc_rescan(const AllocSlabs& A, int G, int nTotArg, int lane, int ldArg) {
+    const int nTot = NTOT ? NTOT : nTotArg, ld = NTOT ? kWave : ldArg;
+    const int gs = NTOT ? alloc_group_size(NTOT) : A.gs;
+    const int b0 = G * gs;
     double v0 = A.run[b0 * ld + lane];
     int i0 = b0;
-    for (int b = b0 + 1; b < b1; ++b) {
-        const double v = A.run[b * ld + lane];
-        if (v > v0) { v0 = v; i0 = b; }
+    if (NTOT) {
+        double v[8];
+#pragma unroll
+        for (int j = 1; j < (NTOT ? alloc_group_size(NTOT ? NTOT : 1) : 1); ++j) v[j] = A.run[min(b0 + j, nTot - 1) * ld + lane];
+#pragma unroll
+        for (int j = 1; j < (NTOT ? alloc_group_size(NTOT ? NTOT : 1) : 1); ++j)
+            if (b0 + j < nTot && v[j] > v0) { v0 = v[j]; i0 = b0 + j; }
+    } else {
+        const int b1 = min(b0 + gs, nTot);
+        for (int b = b0 + 1; b < b1; ++b) {
+            const double v = A.run[b * ld + lane];
+            if (v > v0) { v0 = v; i0 = b; }
+        }
     }
     A.gv[G * ld + lane] = v0;
     A.gi[G * ld + lane] = (unsigned char)i0;
 }
 
-__device__ __forceinline__ double bitalloc_lane(const AllocSlabs& A, int nTot, int maxMantBits, double budget, int lane,
-                                                bool active, int ld = kWave) {
+template <int NTOT = 0>
+__device__ __forceinline__ double bitalloc_lane(const AllocSlabs& A, int nTotArg, int maxMantBits, double budget, int lane,
+                                                bool active, int ldArg = kWave) {
+    const int nTot = NTOT ? NTOT : nTotArg, ld = NTOT ? kWave : ldArg;
+    constexpr int kG = NTOT ? (NTOT + alloc_group_size(NTOT ? NTOT : 1) - 1) / alloc_group_size(NTOT ? NTOT : 1) : 0;
+    const int nG = NTOT ? kG : A.nG;
     double left = budget;
     int retired = 0;
     // every iteration grants (<= maxMantBits-1 times per band) or retires (<= nTot times): the loop ends by
@@ -96,14 +116,23 @@ __device__ __forceinline__ double bitalloc_lane(const AllocSlabs& A, int nTot, i
     int guard = (maxMantBits + 2) * nTot + 8;
     bool live = active && left > 0;
     if (live)
-        for (int G = 0; G < A.nG; ++G) alloc_rescan(A, G, nTot, lane, ld);
+        for (int G = 0; G < nG; ++G) alloc_rescan<NTOT>(A, G, nTot, lane, ld);
     while (__any(live)) {
         if (live) {
             double best = A.gv[lane];
             int G = 0;
-            for (int g = 1; g < A.nG; ++g) {
-                const double v = A.gv[g * ld + lane];
-                if (v > best) { best = v; G = g; }              // np.argmax: first maximum wins
+            if (NTOT) {
+                double gvv[kG ? kG : 1];
+#pragma unroll
+                for (int g = 1; g < kG; ++g) gvv[g] = A.gv[g * ld + lane];
+#pragma unroll
+                for (int g = 1; g < kG; ++g)
+                    if (gvv[g] > best) { best = gvv[g]; G = g; }        // np.argmax: first maximum wins
+            } else {
+                for (int g = 1; g < nG; ++g) {
+                    const double v = A.gv[g * ld + lane];
+                    if (v > best) { best = v; G = g; }                  // np.argmax: first maximum wins
+                }
             }
             const int idx = A.gi[G * ld + lane];
             const int have = A.bits[idx * ld + lane];
@@ -123,13 +152,14 @@ __device__ __forceinline__ double bitalloc_lane(const AllocSlabs& A, int nTot, i
                 if (++retired == nTot) live = false;
             }
             if (!(left > 0) || --guard <= 0) live = false;
-            if (live) alloc_rescan(A, G, nTot, lane, ld);
+            if (live) alloc_rescan<NTOT>(A, G, nTot, lane, ld);
         }
     }
     return left;
 }
 
 // fpw = frames per wave (<= 64; the launcher uses 64, see there).
+template <int NTOT>
 __global__ __launch_bounds__(kWave) void bitalloc_kernel(DevShape S, int joint, int64_t nFrames, int fpw,
                                                          const double* __restrict__ smr,
                                                          const int* __restrict__ msSwitch,
@@ -161,7 +191,7 @@ __global__ __launch_bounds__(kWave) void bitalloc_kernel(DevShape S, int joint, 
     double budget;
     if (joint) { budget = S.budgetJointPre + r; budget -= S.blkswA; budget -= S.blkswB; }   // codecThem.py:390-396
     else budget = S.budgetMono + r;                                                           // codecThem.py:308
-    const double left = bitalloc_lane(A, nTot, S.maxMantBits, budget, lane, active, fpw);
+    const double left = bitalloc_lane<NTOT>(A, nTot, S.maxMantBits, budget, lane, active, fpw);
     if (active) {
         resOut[f] = (int)left;                            // int(bitsLeft): truncation toward zero (bitalloc.py:155)
         for (int i = 0; i < nTot; ++i) bitAlloc[f * nTot + i] = A.bits[i * fpw + lane];
@@ -319,8 +349,11 @@ hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, con
     // the loop is bound by instruction issue, not by latency, so full waves it is.
     const int fpw = kWave;
     const size_t lds = alloc_lds_bytes(nTot, fpw);
-    hipLaunchKernelGGL(bitalloc_kernel, dim3((unsigned)((nFrames + fpw - 1) / fpw)), dim3(kWave), lds, st, S, joint,
-                       nFrames, fpw, smr, msSwitch, resIn, bitAlloc, resOut);
+    const dim3 bgrid((unsigned)((nFrames + fpw - 1) / fpw));
+    // the common band counts (25 bands of a long block at 44.1 / 48 kHz, one or two streams) as compile-time constants
+    if (nTot == 25) hipLaunchKernelGGL(bitalloc_kernel<25>, bgrid, dim3(kWave), lds, st, S, joint, nFrames, fpw, smr, msSwitch, resIn, bitAlloc, resOut);
+    else if (nTot == 50) hipLaunchKernelGGL(bitalloc_kernel<50>, bgrid, dim3(kWave), lds, st, S, joint, nFrames, fpw, smr, msSwitch, resIn, bitAlloc, resOut);
+    else hipLaunchKernelGGL(bitalloc_kernel<0>, bgrid, dim3(kWave), lds, st, S, joint, nFrames, fpw, smr, msSwitch, resIn, bitAlloc, resOut);
     if (ev) (void)hipEventRecord(ev[1], st);
     const int vecOk = !((reinterpret_cast<uintptr_t>(lines) | reinterpret_cast<uintptr_t>(mantissa)) & 15);
     const dim3 qgrid((unsigned)(nFrames * (joint ? 2 : 1)));
