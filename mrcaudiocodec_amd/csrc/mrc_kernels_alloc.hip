@@ -351,7 +351,10 @@ hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, con
     const size_t lds = alloc_lds_bytes(nTot, fpw);
     const dim3 bgrid((unsigned)((nFrames + fpw - 1) / fpw));
     // the common band counts (25 bands of a long block at 44.1 / 48 kHz, one or two streams) as compile-time constants
-    if (nTot == 25) hipLaunchKernelGGL(bitalloc_kernel<25>, bgrid, dim3(kWave), lds, st, S, joint, nFrames, fpw, smr, msSwitch, resIn, bitAlloc, resOut);
+    // (9 / 18: the short and transition blocks)
+    if (nTot == 9) hipLaunchKernelGGL(bitalloc_kernel<9>, bgrid, dim3(kWave), lds, st, S, joint, nFrames, fpw, smr, msSwitch, resIn, bitAlloc, resOut);
+    else if (nTot == 18) hipLaunchKernelGGL(bitalloc_kernel<18>, bgrid, dim3(kWave), lds, st, S, joint, nFrames, fpw, smr, msSwitch, resIn, bitAlloc, resOut);
+    else if (nTot == 25) hipLaunchKernelGGL(bitalloc_kernel<25>, bgrid, dim3(kWave), lds, st, S, joint, nFrames, fpw, smr, msSwitch, resIn, bitAlloc, resOut);
     else if (nTot == 50) hipLaunchKernelGGL(bitalloc_kernel<50>, bgrid, dim3(kWave), lds, st, S, joint, nFrames, fpw, smr, msSwitch, resIn, bitAlloc, resOut);
     else hipLaunchKernelGGL(bitalloc_kernel<0>, bgrid, dim3(kWave), lds, st, S, joint, nFrames, fpw, smr, msSwitch, resIn, bitAlloc, resOut);
     if (ev) (void)hipEventRecord(ev[1], st);
