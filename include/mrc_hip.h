@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define MRC_VERSION 200            /* 0.2.0 */
+#define MRC_VERSION 300            /* 0.3.0 */
 #define MRC_MAX_BANDS 32
 /* how a channel's samples are held: float64 signed fractions (what pcmfile.py:98 hands the codec) or the file's
  * int16 PCM codes (converted on load, pcmfile.py:91-100); how the mantissa plane is stored */
@@ -309,12 +309,73 @@ int mrc_dev_huffman_gain(mrc_handle* h, int a, int b, int64_t n_frames, int n_st
  * (4-byte length + payload each), block_offset [n + 1] the byte offset of every block (last entry: the total);
  * huff_table / bits_saved [n * n_channels] may be NULL.  total_bytes (HOST pointer) non-NULL: the call waits for
  * the stream and returns the total, MRC_ERR_NOMEM if it exceeds out_cap (nothing is written past out_cap; size
- * the buffer with mrc_pack_bound); NULL: fully asynchronous, read block_offset[n] later. */
+ * the buffer with mrc_pack_bound), MRC_ERR_INVALID for a table id outside {0..3, 15} or a chunk beyond mrc_pack_bound
+ * (bit_alloc > 16 handed in); NULL: fully asynchronous, read block_offset[n] later -- the packer's workspace belongs to
+ * the handle, so asynchronous calls on one handle must all be queued on ONE stream, and errors of an asynchronous
+ * call are only seen by mrc_dev_pack_status. */
 int mrc_dev_pack_blocks(mrc_handle* h, int a, int b, int64_t n_blocks, int n_channels, int joint, int use_huffman,
                         const int32_t* huff_table_in, const int32_t* overall_scale, const int32_t* ms_switch,
                         const int32_t* scale_factor, const int32_t* bit_alloc, const void* mantissa, int mantissa_format,
                         uint8_t* out, int64_t out_cap, int64_t* block_offset, int32_t* huff_table, int32_t* bits_saved,
                         int64_t* total_bytes, void* stream);
+/* Waits for `stream` and returns the status of the most recent mrc_dev_pack_blocks on the handle: MRC_OK,
+ * MRC_ERR_INVALID (bad table id / chunk beyond the bound) or MRC_ERR_NOMEM (out_cap exceeded); total_bytes (nullable). */
+int mrc_dev_pack_status(mrc_handle* h, int64_t* total_bytes, void* stream);
+
+/* ---- chained stream encode: the reference's WHOLE encode loop in one call ---------------------------------------
+ * What `python pacfileThem.py in.wav` does in its encode direction for n_streams stereo streams at once -- one
+ * JointWriteDataBlock per block with codingParams.bitReservoir carried from block to block (pacfileThem.py:1159-1214,
+ * 793-972; codecThem.py:262-278, 381-396, 503), then Close()'s block through the non-joint writer (973-984), behind the
+ * file header (586-613) -- given the block shapes (the transient detector's decisions: mrc_transient_peaks +
+ * mrcaudiocodec_amd/transient.py).  The reference runs the whole kernel set once per block because block t+1's bit budget
+ * contains what block t left over; here everything that does not depend on the reservoir (window, MDCT, overall
+ * scale, SMRs, M/S switch: 95 % of the work) runs as ONE batch per block shape over all blocks of all streams, and the
+ * rest (bit allocation -> scale factors -> mantissas -> Huffman pricing -> next reservoir) is a serial scan per stream
+ * ON THE DEVICE, one workgroup per stream, no host round trip and no launch per block; the device packer then writes
+ * the chunks in file order.
+ *   pcm_left / pcm_right [n_streams][stream_stride] int16 PCM codes (converted on load as pcmfile.py:91-100 does); each
+ *     stream starts with its prior hop (zeros at file start, pacfileThem.py:615-618).
+ *   Blocks of stream s: indices block_start[s] .. block_start[s + 1] - 1 of block_offset / block_a / block_b: block i
+ *     reads block_a[i] + block_b[i] samples at block_offset[i] of its stream (the a samples carried over, then the b new
+ *     ones, pacfileThem.py:799-802); shapes are the four of the reference's block switching, (L, L), (L, S), (S, S),
+ *     (S, L) with L = n_mdct_lines, S = n_short.
+ *   reservoir_in [n_streams] (NULL: zeros): codingParams.bitReservoir at the start (pacfileThem.py:1111), e.g. handed
+ *     over from the previous shard of a long stream.
+ *   use_huffman = 0: EncodeNoHuff's raw mantissas (table id 15).  with_flush: append Close()'s two non-joint chunks
+ *     per stream (the stream must then end with a long block, as the reference's Close() assumes).
+ *   num_samples [n_streams] (NULL: no headers): the header's sample count (the WAV's, pacfileThem.py:1103); the header
+ *     of stream s is written in front of its first chunk, so out[stream_byte_offset[s] .. stream_byte_offset[s + 1])
+ *     is the complete `.pac` file of stream s.
+ *   out [out_cap]: size it with mrc_chain_out_bound, or less and retry on MRC_ERR_NOMEM (total_bytes then holds the
+ *     size needed).  item_byte_offset (NULL or [n_items + 1], n_items = blocks + 2 n_streams with_flush): where every
+ *     block's chunks start.  reservoir_out (NULL or [n_streams]): codingParams.bitReservoir after the last block.
+ *     reservoir_trace (NULL or [n_items]): ... after every block (tests).
+ * mrc_dev_encode_chained_pac: the same with pcm_left / pcm_right / out in DEVICE memory (all other pointers host);
+ * it synchronises `stream` before it returns (the byte offsets come back).  mrc_get_chain_ms: device time of the last
+ * chained call -- ms[0] phase A + preparation, ms[1] the serial scan, ms[2] packing, ms[3] all three. */
+int64_t mrc_chain_out_bound(mrc_handle* h, int64_t n_streams, const int64_t* block_start, const int32_t* block_a,
+                            const int32_t* block_b, int with_flush, int with_headers);
+int mrc_encode_chained_stream_pcm16_pac(mrc_handle* h, int64_t n_streams, const int16_t* pcm_left, const int16_t* pcm_right,
+                                        int64_t stream_stride, const int64_t* block_start, const int64_t* block_offset,
+                                        const int32_t* block_a, const int32_t* block_b, const int32_t* reservoir_in,
+                                        int use_huffman, int with_flush, const uint32_t* num_samples, uint8_t* out,
+                                        int64_t out_cap, int64_t* stream_byte_offset, int64_t* item_byte_offset,
+                                        int32_t* reservoir_out, int32_t* reservoir_trace, int64_t* total_bytes);
+/* ... with the samples as MRC_SAMPLES_PCM16 (int16_t*) or MRC_SAMPLES_F64 (double*: the signed fractions pcmfile.py:98
+ * hands the codec -- what the per-block API takes) */
+int mrc_encode_chained_stream_pac(mrc_handle* h, int64_t n_streams, const void* pcm_left, const void* pcm_right,
+                                  int sample_format, int64_t stream_stride, const int64_t* block_start,
+                                  const int64_t* block_offset, const int32_t* block_a, const int32_t* block_b,
+                                  const int32_t* reservoir_in, int use_huffman, int with_flush, const uint32_t* num_samples,
+                                  uint8_t* out, int64_t out_cap, int64_t* stream_byte_offset, int64_t* item_byte_offset,
+                                  int32_t* reservoir_out, int32_t* reservoir_trace, int64_t* total_bytes);
+int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm_left, const void* pcm_right,
+                               int sample_format, int64_t stream_stride, const int64_t* block_start,
+                               const int64_t* block_offset, const int32_t* block_a, const int32_t* block_b,
+                               const int32_t* reservoir_in, int use_huffman, int with_flush, const uint32_t* num_samples,
+                               uint8_t* out, int64_t out_cap, int64_t* stream_byte_offset, int64_t* item_byte_offset,
+                               int32_t* reservoir_out, int32_t* reservoir_trace, int64_t* total_bytes, void* stream);
+int mrc_get_chain_ms(mrc_handle* h, double* ms /*[4]*/);
 
 /* ---- decode side ("next" row f-4: the reference's decoder, pacfileThem.py:130-585 + codecThem.py:30-134) ----
  * Host: header and chunk parsing (no GPU, no handle).  Device: dequantise -> undo the overall scale -> M/S
@@ -364,6 +425,9 @@ int mrc_set_timing(mrc_handle* h, int enabled);
 /* MRC_OPT_SMR_ALL_BANDS = 1: in joint blocks compute the SMRs of all four signals in every band (default 0: only the
  * pair the M/S switch selects per band, ms_stereo.py:70-81 -- the other pair never reaches the bit allocation). */
 #define MRC_OPT_SMR_ALL_BANDS 2
+/* MRC_OPT_CHAIN_FORCE_REPAIR = 1 (tests only): the chained encode's event preparation scrambles its candidate order so
+ * that the repair pass, which otherwise only runs on near-ties that rounding turned round, does real work. */
+#define MRC_OPT_CHAIN_FORCE_REPAIR 3
 int mrc_set_option(mrc_handle* h, int option, int value);
 int mrc_get_stage_ms(mrc_handle* h, double* ms /*[3]*/);
 /* ... and per kernel: ms[0..4] = MDCT, smr_kernel, band_stats_kernel (joint only, else ~0), bitalloc_kernel,

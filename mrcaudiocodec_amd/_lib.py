@@ -105,6 +105,18 @@ def _load():
         "mrc_dev_huffman_gain": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_int] + [C.c_void_p] * 7),
         "mrc_dev_pack_blocks": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 +
                                 [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, _i64p, C.c_void_p]),
+        "mrc_dev_pack_status": (C.c_int, [H, _i64p, C.c_void_p]),
+        "mrc_chain_out_bound": (C.c_int64, [H, C.c_int64, _i64p, _i32p, _i32p, C.c_int, C.c_int]),
+        "mrc_encode_chained_stream_pcm16_pac": (C.c_int, [H, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, _i64p, _i64p, _i32p,
+                                                          _i32p, _i32p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                                          _i64p, _i64p, _i32p, _i32p, _i64p]),
+        "mrc_encode_chained_stream_pac": (C.c_int, [H, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, _i64p, _i64p,
+                                                    _i32p, _i32p, _i32p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                                    _i64p, _i64p, _i32p, _i32p, _i64p]),
+        "mrc_dev_encode_chained_pac": (C.c_int, [H, C.c_int64, C.c_void_p, C.c_void_p, C.c_int, C.c_int64, _i64p, _i64p,
+                                                 _i32p, _i32p, _i32p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64,
+                                                 _i64p, _i64p, _i32p, _i32p, _i64p, C.c_void_p]),
+        "mrc_get_chain_ms": (C.c_int, [H, _f64p]),
         "mrc_pac_read_header": (C.c_int, [_u8p, C.c_int64, C.POINTER(MrcConfig), _i32p, C.POINTER(C.c_uint32), _i64p]),
         "mrc_pac_scan_chunks": (C.c_int64, [_u8p, C.c_int64, C.c_int64, _i64p, C.c_int64]),
         "mrc_unpack_blocks": (C.c_int, [C.POINTER(MrcConfig), C.c_int64, C.c_int, C.c_int, _u8p, C.c_int64, _i64p] +
@@ -371,6 +383,82 @@ class Handle:
             break
         return {"bytes": buf[:int(total[0])], "block_offset": offs, "huff_table": table, "bits_saved": saved,
                 "reservoir_out": res_out}
+
+    # ---- chained stream encode (the reference's whole encode loop in one call)
+    @staticmethod
+    def _chain_schedule(shapes):
+        """shapes[s] = [(offset, a, b), ...] (or an int array [n][3]) -> block_start, offset, a, b arrays."""
+        counts = [len(sh) for sh in shapes]
+        start = np.zeros(len(shapes) + 1, np.int64)
+        start[1:] = np.cumsum(counts)
+        flat = np.concatenate([np.asarray(sh, dtype=np.int64).reshape(-1, 3) for sh in shapes]) if counts and sum(counts) \
+            else np.zeros((0, 3), np.int64)
+        return (start, np.ascontiguousarray(flat[:, 0]), np.ascontiguousarray(flat[:, 1], dtype=np.int32),
+                np.ascontiguousarray(flat[:, 2], dtype=np.int32))
+
+    def encode_chained_pac(self, pcm_left, pcm_right, shapes, use_huffman=True, with_flush=True, num_samples=None,
+                           reservoir_in=None, want_trace=False, device=None, stream=None):
+        """mrc_encode_chained_stream_pac: stereo streams [nStreams][stride] -- int16 PCM codes or float64 signed fractions,
+        each starting with its prior hop -- + the block shapes of every stream -> the `.pac` bytes of every stream (with
+        num_samples: complete files, header included), the bit reservoir carried from block to block on the device.
+        device = (left_ptr, right_ptr, sample_format, stride, out_ptr, out_cap): everything stays in HBM
+        (mrc_dev_encode_chained_pac; `bytes` is then None).
+        -> dict: bytes (uint8), stream_offset [nStreams + 1], item_offset, reservoir_out [nStreams], total, (trace)."""
+        start, off, a, b = self._chain_schedule(shapes)
+        n_streams = len(shapes)
+        if device is None:
+            pl, pr = np.atleast_2d(pcm_left), np.atleast_2d(pcm_right)
+            dt = np.int16 if pl.dtype == np.int16 else np.float64
+            pl, pr = np.ascontiguousarray(pl, dtype=dt), np.ascontiguousarray(pr, dtype=dt)
+            if pl.shape != pr.shape or pl.shape[0] != n_streams:
+                raise ValueError("pcm_left / pcm_right must be [nStreams][stride], one row per shape list")
+            stride, fmt = pl.shape[1], (1 if dt == np.int16 else 0)
+        n_items = len(off) + (2 * n_streams if with_flush else 0)
+        ns = None if num_samples is None else np.ascontiguousarray(num_samples, dtype=np.uint32)
+        if ns is not None and ns.shape != (n_streams,):
+            raise ValueError("num_samples: one value per stream")
+        res_in = _reservoir(reservoir_in, n_streams)
+        s_off = np.zeros(n_streams + 1, np.int64)
+        i_off = np.zeros(n_items + 1, np.int64)
+        res_out = np.zeros(n_streams, np.int32)
+        trace = np.zeros(n_items, np.int32) if want_trace else None
+        total = np.zeros(1, np.int64)
+        vp = lambda arr: None if arr is None else arr.ctypes.data_as(C.c_void_p)
+        sched = (_p(start, _i64p), _p(off, _i64p), _p(a, _i32p), _p(b, _i32p), _p(res_in, _i32p), 1 if use_huffman else 0,
+                 1 if with_flush else 0, vp(ns))
+        tail = (_p(s_off, _i64p), _p(i_off, _i64p), _p(res_out, _i32p), _p(trace, _i32p), total.ctypes.data_as(_i64p))
+        buf = None
+        if device is not None:
+            dl, dr, fmt, stride, dout, dcap = device
+            self._check(lib.mrc_dev_encode_chained_pac(self._h, n_streams, dl, dr, int(fmt), int(stride), *sched, dout, int(dcap),
+                                                       *tail, stream))
+        else:
+            bound = int(lib.mrc_chain_out_bound(self._h, n_streams, _p(start, _i64p), _p(a, _i32p), _p(b, _i32p),
+                                                1 if with_flush else 0, 0 if ns is None else 1))
+            if bound < 0:
+                raise MrcError("mrc_chain_out_bound failed (%d): block shape out of range" % bound)
+            # a first buffer for typical content (~3 bits per sample), the worst case only if that turns out too small
+            cap = min(bound, int(off.size) * 1024 + n_streams * 4096 + 4096)
+            for attempt in (0, 1):
+                buf = np.empty(max(cap, 1), np.uint8)
+                rc = lib.mrc_encode_chained_stream_pac(self._h, n_streams, vp(pl), vp(pr), fmt, stride, *sched, vp(buf),
+                                                       buf.size, *tail)
+                if rc == MRC_ERR_NOMEM and attempt == 0 and cap < bound:
+                    cap = bound
+                    continue
+                self._check(rc)
+                break
+            buf = buf[:int(total[0])]
+        out = {"bytes": buf, "stream_offset": s_off, "item_offset": i_off, "reservoir_out": res_out, "total": int(total[0])}
+        if want_trace:
+            out["reservoir_trace"] = trace
+        return out
+
+    def chain_ms(self):
+        """device time of the last chained encode: phase A + preparation, serial scan, packing, all three (ms)"""
+        ms = np.zeros(4, np.float64)
+        self._check(lib.mrc_get_chain_ms(self._h, _p(ms, _f64p)))
+        return ms
 
     def pcm_to_float(self, pcm):
         pcm = np.ascontiguousarray(pcm, dtype=np.int16)

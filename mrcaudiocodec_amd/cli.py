@@ -21,8 +21,9 @@ import numpy as np
 from . import Handle, pacfile, transient
 
 
-def read_wav(path, hop=1024):
-    """-> (sample_rate, n_channels, num_samples, float64 [nCh][nHops*hop]), last hop zero padded."""
+def read_wav(path, hop=1024, want_pcm=False):
+    """-> (sample_rate, n_channels, num_samples, float64 [nCh][nHops*hop]), last hop zero padded; want_pcm: the int16
+    codes themselves, padded alike, as a fifth item."""
     with open(path, "rb") as fp:
         head = fp.read(12)
         if head[0:4] != b"RIFF" or head[8:12] != b"WAVE":
@@ -44,32 +45,43 @@ def read_wav(path, hop=1024):
                 break
         num_samples = unpack("<L", fp.read(4))[0] // (n_ch * 2)
         raw = fp.read(num_samples * n_ch * 2)
-    c = np.frombuffer(raw, dtype="<i2").astype(np.float64)
-    c = c[:(len(c) // n_ch) * n_ch].reshape(-1, n_ch).T
-    n_hops = -(-c.shape[1] // hop)
-    x = np.zeros((n_ch, n_hops * hop))
+    codes = np.frombuffer(raw, dtype="<i2")
+    codes = codes[:(len(codes) // n_ch) * n_ch].reshape(-1, n_ch).T
+    n_hops = -(-codes.shape[1] // hop)
+    pcm = np.zeros((n_ch, n_hops * hop), np.int16)
+    pcm[:, :codes.shape[1]] = codes
+    c = pcm.astype(np.float64)
     mag = np.abs(c)
-    x[:, :c.shape[1]] = np.where(mag >= 32768, 0.0, np.sign(c) * 2.0 * mag / 65535)    # -32768 -> 0.0 (pcmfile.py:91-100)
-    return rate, n_ch, num_samples, x
+    x = np.where(mag >= 32768, 0.0, np.sign(c) * 2.0 * mag / 65535)    # -32768 -> 0.0 (pcmfile.py:91-100)
+    return (rate, n_ch, num_samples, x, pcm) if want_pcm else (rate, n_ch, num_samples, x)
 
 
 def encode_wav(in_path, out_path=None, use_huffman=True, device_id=0, handle=None, exact_spread=False):
     """exact_spread: evaluate the masker spreading operation by operation like psychoac.py:68-78 (MRC_OPT_EXACT_SPREAD,
-    ~30x slower kernel; irrelevant for the time of one file).  Both modes give the reference driver's bytes on every
-    fixture and sweep; neither is bit-identical by construction (README.md, "Parity")."""
-    rate, n_ch, num_samples, hops = read_wav(in_path)
+    ~30x slower kernel).  Both modes give the reference driver's bytes on every fixture and sweep; neither is
+    bit-identical by construction (README.md, "Parity").
+    The whole file is encoded by ONE library call (mrc_encode_chained_stream_pcm16_pac): int16 codes in, `.pac` bytes out."""
+    rate, n_ch, num_samples, hops, pcm = read_wav(in_path, want_pcm=True)
     if n_ch != 2:
         raise ValueError("stereo input only (the reference's JointEncode indexes data[0], data[1])")
     h = handle if handle is not None else Handle(sample_rate=rate, device_id=device_id)
-    h.set_option(1, 1 if exact_spread else 0)
+    if exact_spread:
+        h.set_option(1, 1)
     try:
-        stream = np.concatenate([np.zeros((2, h.cfg.n_mdct_lines)), hops], axis=1)
+        L = h.cfg.n_mdct_lines
+        stream = np.concatenate([np.zeros((2, L)), hops], axis=1)
         shapes = transient.block_shapes(h, stream)
         if not shapes:
             raise ValueError("file too short: fewer than two hops")
-        data = pacfile.encode_stereo_stream(h, stream, shapes, use_huffman, num_samples=num_samples)
+        codes = np.concatenate([np.zeros((2, L), np.int16), pcm], axis=1)
+        if shapes[-1][2] != L:
+            raise ValueError("the stream must end with a long block (the reference's Close() assumes it)")
+        r = h.encode_chained_pac(codes[0][None], codes[1][None], [shapes], use_huffman=use_huffman, with_flush=True,
+                                 num_samples=[num_samples])
+        data = r["bytes"].tobytes()
     finally:
-        h.set_option(1, 0)
+        if exact_spread and handle is not None:
+            h.set_option(1, 0)                   # (a caller's handle gets back the default it came with only if WE changed it)
         if handle is None:
             h.close()
     if out_path:

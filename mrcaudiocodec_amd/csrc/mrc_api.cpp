@@ -1,112 +1,22 @@
 // C ABI of libmrc_hip.so (include/mrc_hip.h): handle, shape cache, workspace, host<->device staging.
 // No computation happens here and there is no CPU fallback: every entry point ends in a kernel launch
 // of mrc_kernels.hip or fails.
-#include "mrc_internal.hpp"
+#include "mrc_handle.hpp"
 
 #include <cstdio>
 #include <cstring>
-#include <map>
-#include <mutex>
 #include <new>
-#include <utility>
 
 using namespace mrc;
 
-namespace {
+namespace mrc {
 
-std::string g_create_error;
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t bytes) {
-        if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr; cap = 0;
-        size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
-    template <class T> T* as() { return (T*)p; }
-};
-
-}  // namespace
-
-// intermediate results of one encode call (lines, SMRs, band peaks); one set per stream that encodes concurrently
-struct Workspace {
-    DevBuf lines, smr, peak;
-    void release() { lines.release(); smr.release(); peak.release(); }
-};
-
-// The pipelined host entry point runs THREE streams -- one that only copies in, one that only launches kernels, one that
-// only copies out -- over a ring of chunk buffers (lanes), ordered by events: measured on the MI355X box, page-locked
-// copies reach 42-48 GB/s each way with ONE stream per direction and drop to 19-25 GB/s with three streams that each
-// copy both ways (tools/pcie_rates.py), which is what one-stream-per-chunk pipelining amounts to.
-struct Lane {
-    DevBuf pcmL, pcmR, resIn, oScale, ms, ba, sf, mant, resOut;
-    DevBuf pacBytes, pacOffs, pacTable, pacSaved;                // mrc_encode_stream_pcm16_pac: the chunk's packed form
-    long long* pacTotal = nullptr;                               // page-locked: the chunk's byte count, read by the host
-    hipEvent_t evIn = nullptr, evK = nullptr, evOut = nullptr;   // chunk copied in / encoded / copied out
-    void release() {
-        for (DevBuf* b : {&pcmL, &pcmR, &resIn, &oScale, &ms, &ba, &sf, &mant, &resOut, &pacBytes, &pacOffs, &pacTable, &pacSaved})
-            b->release();
-        if (pacTotal) (void)hipHostFree(pacTotal);
-        pacTotal = nullptr;
-        for (hipEvent_t* e : {&evIn, &evK, &evOut}) {
-            if (*e) (void)hipEventDestroy(*e);
-            *e = nullptr;
-        }
-    }
-};
-constexpr int kLanes = 4;          // chunk buffers in flight (mrc_encode_stream_pcm16_pac reads sizes two chunks behind)
-constexpr int kKernelEvents = 6;     // boundaries of: mdct | smr | band_stats | bitalloc | quantize
-
-struct mrc_handle {
-    mrc_config cfg{};
-    int device = 0;
-    hipStream_t stream = nullptr;
-    std::map<std::pair<int, int>, HostShape> shapes;
-    std::string error;
-    Workspace ws;                    // workspace of mrc_dev_encode* (calls on one handle are serialised)
-    Lane lanes[kLanes];              // mrc_encode_stream_pcm16: chunk buffers ...
-    hipStream_t stIn = nullptr, stOut = nullptr;   // ... and its copy-in / copy-out streams; the kernels of all chunks run
-    Workspace wsPipe;                //     on `stream`, one after the other: one workspace.  (No third stream of its own:
-                                     //     the runtime multiplexes streams onto 4 hardware queues by default -- with the
-                                     //     null stream and `stream` that is exactly four; a fifth would share a queue with
-                                     //     one of the others and serialise with it: 10 000 instead of 19 000 Msamples/s)
-    // staging of the host entry points
-    DevBuf inL, inR, inAux, inAux2, inAux3, outA, outB, outC, outD, outE, outF, outG;
-    DevBuf packWs;                   // mrc_dev_pack_blocks: chunk sizes / positions / (table ids)
-    bool timing = false;
-    bool exactSpread = false;        // mrc_set_option(MRC_OPT_EXACT_SPREAD)
-    bool smrAllBands = false;        // mrc_set_option(MRC_OPT_SMR_ALL_BANDS)
-    hipEvent_t ev[kKernelEvents] = {};
-    double stageMs[3] = {0, 0, 0};
-    double kernelMs[5] = {0, 0, 0, 0, 0};
-};
-
-namespace {
-
-int fail(mrc_handle* h, int code, const std::string& msg) {
-    if (h) h->error = msg; else g_create_error = msg;
-    return code;
+std::string& create_error() {
+    static std::string s;
+    return s;
 }
-
-int hip_fail(mrc_handle* h, hipError_t e, const char* what) {
-    return fail(h, MRC_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
-}
-
-#define MRC_HIP(h, call)                                              \
-    do {                                                              \
-        hipError_t e_ = (call);                                       \
-        if (e_ != hipSuccess) return hip_fail((h), e_, #call);        \
-    } while (0)
 
 int get_shape(mrc_handle* h, int a, int b, const HostShape** out) {
-    // every entry point that launches comes through here first: the launches, the tables and the caller's pointers
-    // all belong to the handle's device, whatever the calling thread's current device was
     MRC_HIP(h, hipSetDevice(h->device));
     auto key = std::make_pair(a, b);
     auto it = h->shapes.find(key);
@@ -120,14 +30,7 @@ int get_shape(mrc_handle* h, int a, int b, const HostShape** out) {
     return MRC_OK;
 }
 
-bool all_bands_non_empty(const HostShape& hs) {
-    for (int n : hs.bandN) if (n <= 0) return false;
-    return true;
-}
-
-hipStream_t pick_stream(mrc_handle* h, void* stream) { return stream ? (hipStream_t)stream : h->stream; }
-
-}  // namespace
+}  // namespace mrc
 
 extern "C" {
 
@@ -183,7 +86,7 @@ int mrc_create(const mrc_config* cfg, mrc_handle** out) {
     for (auto& s : shapes) {
         const HostShape* hs;
         int rc = get_shape(h, s[0], s[1], &hs);
-        if (rc != MRC_OK) { g_create_error = h->error; mrc_destroy(h); return rc; }
+        if (rc != MRC_OK) { create_error() = h->error; mrc_destroy(h); return rc; }
     }
     *out = h;
     return MRC_OK;
@@ -201,6 +104,7 @@ void mrc_destroy(mrc_handle* h) {
     for (auto& lane : h->lanes) lane.release();
     h->wsPipe.release();
     h->packWs.release();
+    h->chain.release();
     h->ws.release();
     for (DevBuf* b : {&h->inL, &h->inR, &h->inAux, &h->inAux2, &h->inAux3,
                       &h->outA, &h->outB, &h->outC, &h->outD, &h->outE, &h->outF, &h->outG})
@@ -210,7 +114,7 @@ void mrc_destroy(mrc_handle* h) {
     delete h;
 }
 
-const char* mrc_last_error(const mrc_handle* h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+const char* mrc_last_error(const mrc_handle* h) { return h ? h->error.c_str() : create_error().c_str(); }
 
 int mrc_shape_bands(mrc_handle* h, int a, int b, int32_t* n_bands, int32_t* n_lines) {
     if (!h || !n_bands) return fail(h, MRC_ERR_INVALID, "mrc_shape_bands: null argument");
@@ -245,6 +149,7 @@ int mrc_set_option(mrc_handle* h, int option, int value) {
     if (!h) return MRC_ERR_INVALID;
     if (option == MRC_OPT_EXACT_SPREAD) { h->exactSpread = value != 0; return MRC_OK; }
     if (option == MRC_OPT_SMR_ALL_BANDS) { h->smrAllBands = value != 0; return MRC_OK; }
+    if (option == MRC_OPT_CHAIN_FORCE_REPAIR) { h->chainForceFallback = value != 0; return MRC_OK; }
     return fail(h, MRC_ERR_INVALID, "mrc_set_option: unknown option");
 }
 
@@ -377,6 +282,8 @@ int mrc_dev_pack_blocks(mrc_handle* h, int a, int b, int64_t n_blocks, int n_cha
     MRC_HIP(h, launch_pack(S, P, tables, n_blocks, overall_scale, ms_switch, scale_factor, bit_alloc, mantissa,
                            mantissa_format, huff_table_in, tableOut, bits_saved, out, (long long)out_cap,
                            reinterpret_cast<long long*>(block_offset), h->packWs.p, bound, all_bands_non_empty(*hs), st));
+    h->packLastChunks = nChunks;
+    h->packLastCap = out_cap;
     if (total_bytes) {                                 // the caller wants the size now: one synchronisation
         long long total = 0;
         int bad = 0;
@@ -384,19 +291,65 @@ int mrc_dev_pack_blocks(mrc_handle* h, int a, int b, int64_t n_blocks, int n_cha
         MRC_HIP(h, hipMemcpyAsync(&bad, pack_error_flag(h->packWs.p, nChunks), sizeof(bad), hipMemcpyDeviceToHost, st));
         MRC_HIP(h, hipStreamSynchronize(st));
         *total_bytes = total;
-        if (bad) return fail(h, MRC_ERR_INVALID, "mrc_dev_pack_blocks: huff_table_in holds an id that is neither 0..3 nor 15");
-        if (total > out_cap) return fail(h, MRC_ERR_NOMEM, "mrc_dev_pack_blocks: out_cap too small (see total_bytes)");
+        if (bad & 1) return fail(h, MRC_ERR_INVALID, "mrc_dev_pack_blocks: huff_table_in holds an id that is neither 0..3 nor 15");
+        if (bad & 2)
+            return fail(h, MRC_ERR_INVALID, "mrc_dev_pack_blocks: a chunk is larger than mrc_pack_bound allows (bit_alloc beyond "
+                                            "16 bits?) and was not written");
+        if (total > out_cap || (bad & 4)) return fail(h, MRC_ERR_NOMEM, "mrc_dev_pack_blocks: out_cap too small (see total_bytes)");
     }
+    return MRC_OK;
+}
+
+int mrc_dev_pack_status(mrc_handle* h, int64_t* total_bytes, void* stream) {
+    if (!h) return MRC_ERR_INVALID;
+    if (total_bytes) *total_bytes = 0;
+    if (!h->packLastChunks || !h->packWs.p) return MRC_OK;
+    MRC_HIP(h, hipSetDevice(h->device));
+    hipStream_t st = pick_stream(h, stream);
+    long long total = 0;
+    int bad = 0;
+    MRC_HIP(h, hipMemcpyAsync(&total, pack_total_bytes(h->packWs.p, h->packLastChunks), sizeof(total), hipMemcpyDeviceToHost, st));
+    MRC_HIP(h, hipMemcpyAsync(&bad, pack_error_flag(h->packWs.p, h->packLastChunks), sizeof(bad), hipMemcpyDeviceToHost, st));
+    MRC_HIP(h, hipStreamSynchronize(st));
+    if (total_bytes) *total_bytes = total;
+    if (bad & 3) return fail(h, MRC_ERR_INVALID, "mrc_dev_pack_blocks: bad table id or a chunk beyond mrc_pack_bound");
+    if (total > h->packLastCap || (bad & 4)) return fail(h, MRC_ERR_NOMEM, "mrc_dev_pack_blocks: out_cap too small");
     return MRC_OK;
 }
 
 }  // extern "C"
 
+namespace mrc {
+
+// Phase A of the per-block path -- everything that does not depend on the bit reservoir: windowed MDCT + overall scale
+// -> [M/S switch] -> SMRs and per-band peaks.  The M/S decision needs only the L / R lines (codecThem.py:436); made
+// BEFORE the SMRs, it tells smr_kernel which of the four signals' SMRs the encoder will use per band
+// (ms_stereo.py:70-81) -- the others are not computed.  Event order on the stream when timing: 0 | mdct | 1 | ms_switch
+// | 2 | smr | 3.
+int encode_phase_a(mrc_handle* h, const DevShape& S, int64_t n, const void* chL, const void* chR, int fmt, int64_t stride,
+                   const int64_t* offsets, double* lines, int32_t* oscale, int32_t* msSwitch, double* smr, double* peak,
+                   hipStream_t st, bool timing) {
+    const int joint = chR ? 1 : 0;
+    if (timing) MRC_HIP(h, hipEventRecord(h->ev[0], st));
+    MRC_HIP(h, launch_mdct(S, n, chL, chR, fmt, stride, offsets, true, lines, oscale, st));
+    if (timing) MRC_HIP(h, hipEventRecord(h->ev[1], st));
+    if (joint)
+        MRC_HIP(h, launch_ms_switch(n, S.nBands, S.msLeaves, S.msInternal, S.msPlan, lines, lines + S.halfN,
+                                    4 * (int64_t)S.halfN, msSwitch, st));
+    if (timing) MRC_HIP(h, hipEventRecord(h->ev[2], st));
+    MRC_HIP(h, launch_smr(S, n, chL, chR, fmt, stride, offsets, lines, oscale, smr, nullptr, peak,
+                          (joint && !h->smrAllBands) ? msSwitch : nullptr, h->exactSpread, st));
+    if (timing) MRC_HIP(h, hipEventRecord(h->ev[3], st));
+    return MRC_OK;
+}
+
+}  // namespace mrc
+
 namespace {
 
-// The whole per-block path for n blocks of one shape, queued on `st`: windowed MDCT + overall scale -> SMRs (and
-// per-band peaks) -> [M/S switch] -> bit allocation -> scale factors + mantissas.  Inputs and outputs are device
-// pointers; `ws` holds the intermediate results and must not be shared with a call running on another stream.
+// The whole per-block path for n blocks of one shape, queued on `st`: phase A, then bit allocation -> scale factors +
+// mantissas.  Inputs and outputs are device pointers; `ws` holds the intermediate results and must not be shared with a
+// call running on another stream.
 int encode_core(mrc_handle* h, const DevShape& S, int64_t n, const void* chL, const void* chR, int fmt, int64_t stride,
                 const int64_t* offsets, const int32_t* resIn, int32_t* oscale, int32_t* msSwitch, int32_t* bitAlloc,
                 int32_t* scaleFactor, void* mantissa, int mantFmt, int32_t* resOut, double* linesOut, Workspace& ws,
@@ -412,18 +365,8 @@ int encode_core(mrc_handle* h, const DevShape& S, int64_t n, const void* chL, co
     MRC_HIP(h, ws.peak.reserve(alloc_workspace_bytes(S, n, joint)));
     double* smr = ws.smr.as<double>();
     const bool timing = h->timing;
-    if (timing) MRC_HIP(h, hipEventRecord(h->ev[0], st));
-    MRC_HIP(h, launch_mdct(S, n, chL, chR, fmt, stride, offsets, true, lines, oscale, st));
-    if (timing) MRC_HIP(h, hipEventRecord(h->ev[1], st));
-    // the M/S decision needs only the L / R lines (codecThem.py:436); made BEFORE the SMRs, it tells smr_kernel which
-    // of the four signals' SMRs the encoder will use per band (ms_stereo.py:70-81) -- the others are not computed
-    if (joint)
-        MRC_HIP(h, launch_ms_switch(n, S.nBands, S.msLeaves, S.msInternal, S.msPlan, lines, lines + S.halfN,
-                                    4 * (int64_t)S.halfN, msSwitch, st));
-    if (timing) MRC_HIP(h, hipEventRecord(h->ev[2], st));
-    MRC_HIP(h, launch_smr(S, n, chL, chR, fmt, stride, offsets, lines, oscale, smr, nullptr, ws.peak.as<double>(),
-                          (joint && !h->smrAllBands) ? msSwitch : nullptr, h->exactSpread, st));
-    if (timing) MRC_HIP(h, hipEventRecord(h->ev[3], st));
+    MRC_TRY(encode_phase_a(h, S, n, chL, chR, fmt, stride, offsets, lines, oscale, msSwitch, smr, ws.peak.as<double>(), st,
+                           timing));
     MRC_HIP(h, launch_alloc_quant(S, n, joint, lines, oscale, smr, resIn, msSwitch, bitAlloc, scaleFactor, mantissa,
                                   mantFmt, resOut, ws.peak.as<double>(), true, true, timing ? &h->ev[3] : nullptr, st));
     if (timing) {
@@ -495,12 +438,6 @@ struct Staged {
         return MRC_OK;
     }
 };
-
-#define MRC_TRY(expr)              \
-    do {                           \
-        int rc_ = (expr);          \
-        if (rc_ != MRC_OK) return rc_; \
-    } while (0)
 
 int encode_host(mrc_handle* h, int64_t n, int a, int b, const double* left, const double* right,
                 const int32_t* reservoir_in, int32_t* overall_scale, int32_t* ms_switch, int32_t* scale_factor,
@@ -735,7 +672,7 @@ int mrc_encode_stream_pcm16_pac(mrc_handle* h, int64_t n_frames, const int16_t* 
         do {
             MRC_Q(hipEventSynchronize(lane.evK));
             const long long total = lane.pacTotal[0];
-            if (lane.pacTotal[1]) { rc = fail(h, MRC_ERR_INVALID, "mrc_encode_stream_pcm16_pac: internal table id out of range"); break; }
+            if (lane.pacTotal[1] & 3) { rc = fail(h, MRC_ERR_INVALID, "mrc_encode_stream_pcm16_pac: internal error (table id / chunk size out of range)"); break; }
             base[(size_t)c + 1] = base[(size_t)c] + total;
             if (base[(size_t)c + 1] > out_cap) { rc = fail(h, MRC_ERR_NOMEM, "mrc_encode_stream_pcm16_pac: out_cap too small"); break; }
             hipStream_t so = h->stOut;

@@ -1,0 +1,350 @@
+// C ABI, chained stream encode (include/mrc_hip.h: mrc_encode_chained_stream_pcm16_pac, mrc_dev_encode_chained_pac):
+// the encode direction of the reference's command line (pacfileThem.py:1159-1214, Close() 973-984, file header 586-613)
+// for whole stereo streams in ONE call, block shapes in, `.pac` bytes out.
+//
+//   phase A   per block shape, ONE launch set over all blocks of all streams: windowed MDCT, overall scale, M/S switch,
+//             SMRs, band peaks (the batch kernels) -- nothing here depends on the bit reservoir;
+//   prep      per block: the lines of the two coded streams selected and scaled, the bit allocation's grant events sorted
+//             (chain_prep_kernel);
+//   phase B   one workgroup per stream walks its blocks in file order with the reservoir carried from block to block on
+//             the device (chain_phase_b_kernel): bit allocation, scale factors, mantissas, Huffman pricing;
+//   pack      per block shape plan / write kernels of the device packer around ONE prefix sum over all chunks in file
+//             order, the file headers in front of every stream.
+// No computation happens in this file.
+#include "mrc_handle.hpp"
+
+#include <cstring>
+#include <vector>
+
+using namespace mrc;
+
+namespace {
+
+struct SyncGuard {                    // whichever way we leave: nothing queued still reads the host vectors declared before it
+    hipStream_t st;
+    ~SyncGuard() { if (st) (void)hipStreamSynchronize(st); }
+};
+
+template <class T>
+int upload(mrc_handle* h, DevBuf& buf, const std::vector<T>& v, hipStream_t st) {
+    MRC_HIP(h, buf.reserve(v.empty() ? 1 : v.size() * sizeof(T)));
+    if (!v.empty()) MRC_HIP(h, hipMemcpyAsync(buf.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    return MRC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mrc_get_chain_ms(mrc_handle* h, double* ms) {
+    if (!h || !ms) return MRC_ERR_INVALID;
+    for (int i = 0; i < 4; ++i) ms[i] = h->chainMs[i];
+    return MRC_OK;
+}
+
+int64_t mrc_chain_out_bound(mrc_handle* h, int64_t n_streams, const int64_t* block_start, const int32_t* block_a,
+                            const int32_t* block_b, int with_flush, int with_headers) {
+    if (!h || n_streams < 0 || !block_start || !block_a || !block_b) return MRC_ERR_INVALID;
+    const int L = h->cfg.n_mdct_lines;
+    int64_t total = 0;
+    for (int64_t i = block_start[0]; i < block_start[n_streams]; ++i) {
+        const int64_t bnd = mrc_pack_bound(&h->cfg, block_a[i], block_b[i], 2, 1);
+        if (bnd < 0) return MRC_ERR_INVALID;
+        total += bnd;
+    }
+    if (with_flush) total += n_streams * mrc_pack_bound(&h->cfg, L, L, 2, 0);
+    if (with_headers) total += n_streams * 128;
+    return total;
+}
+
+int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm_left, const void* pcm_right,
+                               int sample_format, int64_t stream_stride, const int64_t* block_start, const int64_t* block_offset,
+                               const int32_t* block_a, const int32_t* block_b, const int32_t* reservoir_in,
+                               int use_huffman, int with_flush, const uint32_t* num_samples, uint8_t* out, int64_t out_cap,
+                               int64_t* stream_byte_offset, int64_t* item_byte_offset, int32_t* reservoir_out,
+                               int32_t* reservoir_trace, int64_t* total_bytes, void* stream) {
+    if (!h || n_streams < 0 || !pcm_left || !pcm_right || stream_stride <= 0 || !block_start || !block_offset ||
+        !block_a || !block_b || !out || out_cap < 0 || !stream_byte_offset || !total_bytes ||
+        (sample_format != MRC_SAMPLES_F64 && sample_format != MRC_SAMPLES_PCM16))
+        return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: bad argument");
+    const size_t sampleBytes = sample_format == MRC_SAMPLES_PCM16 ? sizeof(int16_t) : sizeof(double);
+    *total_bytes = 0;
+    stream_byte_offset[0] = 0;
+    if (n_streams == 0) return MRC_OK;
+    const mrc_config& cfg = h->cfg;
+    const int L = cfg.n_mdct_lines, Sh = cfg.n_short;
+    const int64_t b0 = block_start[0], nB = block_start[n_streams] - b0;
+    if (nB < n_streams) return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: every stream needs at least one block");
+    // ---- the block shapes of the reference's block switching (pacfileThem.py:1192-1210); group 4: Close()'s blocks
+    const int shapeA[kChainGroups] = {L, L, Sh, Sh, L}, shapeB[kChainGroups] = {L, Sh, Sh, L, L};
+    const int nGroups = with_flush ? kChainGroups : kChainGroups - 1;
+    const HostShape* hs[kChainGroups] = {};
+    for (int g = 0; g < nGroups; ++g) {
+        MRC_TRY(get_shape(h, shapeA[g], shapeB[g], &hs[g]));
+        const DevShape& S = hs[g]->dev;
+        const int nTot = (g == 4 ? 1 : 2) * S.nBands;
+        if (nTot > 64 || S.maxMantBits < 2 || S.maxMantBits > 16 || (S.halfN & 3))
+            return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: shape outside what the chained back end covers "
+                                            "(<= 32 bands, 2..16 mantissa bits, lines a multiple of 4)");
+    }
+    // ---- the schedule: items (group << 28 | index inside the group) per stream in file order
+    const int64_t nItems = nB + (with_flush ? 2 * n_streams : 0);
+    const int64_t nChunks = 2 * nB + (with_flush ? 2 * n_streams : 0);
+    std::vector<int32_t> items((size_t)nItems);
+    std::vector<long long> itemStart((size_t)n_streams + 1), firstChunk((size_t)n_streams), tailOff((size_t)n_streams);
+    std::vector<long long> itemChunk((size_t)nItems + 1);
+    std::vector<int32_t> chunkStream((size_t)nChunks);
+    std::vector<int64_t> offs[kChainGroups];
+    std::vector<long long> chunkMap[kChainGroups];
+    std::vector<int32_t> resIn((size_t)n_streams, 0);
+    {
+        int64_t it = 0, ch = 0;
+        for (int64_t s = 0; s < n_streams; ++s) {
+            itemStart[(size_t)s] = it;
+            firstChunk[(size_t)s] = ch;
+            const int64_t i0 = block_start[s], i1 = block_start[s + 1];
+            if (i1 <= i0) return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: every stream needs at least one block");
+            for (int64_t i = i0; i < i1; ++i) {
+                const int a = block_a[i], b = block_b[i];
+                int g = -1;
+                for (int q = 0; q < 4; ++q) if (a == shapeA[q] && b == shapeB[q]) { g = q; break; }   // (L == Sh: group 0)
+                if (g < 0) return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: block shape is not one of (L,L), (L,S), (S,S), (S,L)");
+                const int64_t off = block_offset[i];
+                if (off < 0 || off + a + b > stream_stride)
+                    return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: block reaches outside its stream");
+                if (offs[g].size() >= (size_t)1 << 28) return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: too many blocks of one shape");
+                items[(size_t)it] = (int32_t)((unsigned)g << 28 | (unsigned)offs[g].size());
+                offs[g].push_back(s * stream_stride + off);
+                chunkMap[g].push_back(ch); chunkMap[g].push_back(ch + 1);
+                itemChunk[(size_t)it] = ch;
+                chunkStream[(size_t)ch] = chunkStream[(size_t)ch + 1] = (int32_t)s;
+                ch += 2; ++it;
+            }
+            if (with_flush) {
+                if (block_b[i1 - 1] != L)
+                    return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: a stream must end with a long block (the reference's "
+                                                    "Close() assumes it, pacfileThem.py:973-984)");
+                tailOff[(size_t)s] = block_offset[i1 - 1] + block_a[i1 - 1];
+                for (int c = 0; c < 2; ++c) {                      // codec.Encode: channel after channel
+                    items[(size_t)it] = (int32_t)(4u << 28 | (unsigned)(2 * s + c));
+                    chunkMap[4].push_back(ch);
+                    itemChunk[(size_t)it] = ch;
+                    chunkStream[(size_t)ch] = (int32_t)s;
+                    ++ch; ++it;
+                }
+            }
+            if (reservoir_in) resIn[(size_t)s] = reservoir_in[s];
+        }
+        itemStart[(size_t)n_streams] = it;
+        itemChunk[(size_t)nItems] = ch;
+    }
+    // ---- file headers (pacfileThem.py:586-613)
+    int hdrLen = 0;
+    std::vector<uint8_t> hdr;
+    if (num_samples) {
+        uint8_t one[256];
+        int64_t len = 0;
+        for (int64_t s = 0; s < n_streams; ++s) {
+            if (mrc_pac_header(&cfg, 2, num_samples[s], one, sizeof(one), &len) != MRC_OK)
+                return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: mrc_pac_header failed");
+            if (s == 0) { hdrLen = (int)len; hdr.resize((size_t)n_streams * len); }
+            std::memcpy(hdr.data() + s * len, one, (size_t)len);
+        }
+    }
+
+    MRC_HIP(h, hipSetDevice(h->device));
+    hipStream_t st = pick_stream(h, stream);
+    ChainBufs& C = h->chain;
+    for (auto& e : C.evT) if (!e) MRC_HIP(h, hipEventCreate(&e));
+    std::vector<long long> pos((size_t)nChunks + 1);
+    std::vector<int32_t> resOut((size_t)n_streams);
+    long long total = 0;
+    int bad = 0;
+    SyncGuard guard{st};
+    MRC_HIP(h, hipEventRecord(C.evT[0], st));
+    MRC_TRY(upload(h, C.items, items, st));
+    MRC_TRY(upload(h, C.itemStart, itemStart, st));
+    MRC_TRY(upload(h, C.reservoir, resIn, st));
+    MRC_TRY(upload(h, C.chunkStream, chunkStream, st));
+    MRC_TRY(upload(h, C.hdr, hdr, st));
+    if (reservoir_trace) MRC_HIP(h, C.resTrace.reserve((size_t)nItems * sizeof(int32_t)));
+    if (with_flush) {
+        // the tail offsets ride in the offsets buffer of group 4 (its blocks are laid out explicitly, stride 2 L)
+        MRC_TRY(upload(h, C.g[4].offsets, tailOff, st));
+        MRC_HIP(h, C.flushPcm.reserve((size_t)n_streams * 2 * 2 * L * sampleBytes));
+        MRC_HIP(h, launch_chain_flush_gather(n_streams, L, pcm_left, pcm_right, sample_format, stream_stride,
+                                             C.g[4].offsets.as<long long>(), C.flushPcm.p, st));
+    }
+    // ---- phase A + prep, per block shape
+    ChainGroupDev desc[kChainGroups];
+    std::memset(desc, 0, sizeof(desc));
+    int64_t count[kChainGroups] = {};
+    for (int g = 0; g < nGroups; ++g) {
+        const DevShape& S = hs[g]->dev;
+        const int joint = g == 4 ? 0 : 1, nsig = joint ? 4 : 1, nstream = joint ? 2 : 1;
+        const int64_t m = g == 4 ? 2 * n_streams : (int64_t)offs[g].size();
+        count[g] = m;
+        ChainGroupBufs& B = C.g[g];
+        const int nTot = nstream * S.nBands, nEv = (int)chain_events_per_block(S, joint);
+        if (m > 0) {
+            if (g != 4) MRC_TRY(upload(h, B.offsets, offs[g], st));
+            MRC_TRY(upload(h, B.chunkMap, chunkMap[g], st));
+            MRC_HIP(h, B.lines.reserve((size_t)m * nsig * S.halfN * sizeof(double)));
+            MRC_HIP(h, B.oscale.reserve((size_t)m * nsig * sizeof(int32_t)));
+            MRC_HIP(h, B.smr.reserve((size_t)m * nsig * S.nBands * sizeof(double)));
+            MRC_HIP(h, B.peak.reserve((size_t)m * nsig * S.nBands * sizeof(double)));
+            MRC_HIP(h, B.ms.reserve((size_t)m * S.nBands * sizeof(int32_t)));
+            MRC_HIP(h, B.xsel.reserve((size_t)m * nstream * S.halfN * sizeof(double)));
+            MRC_HIP(h, B.peakSel.reserve((size_t)m * nTot * sizeof(double)));
+            MRC_HIP(h, B.ev.reserve((size_t)m * nEv * sizeof(unsigned)));
+            MRC_HIP(h, B.pre.reserve((size_t)m * (nEv + 1) * sizeof(unsigned)));
+            MRC_HIP(h, B.pos.reserve((size_t)m * nEv * sizeof(unsigned short)));
+            MRC_HIP(h, B.bitAlloc.reserve((size_t)m * nTot * sizeof(int32_t)));
+            MRC_HIP(h, B.scaleFactor.reserve((size_t)m * nTot * sizeof(int32_t)));
+            MRC_HIP(h, B.mant.reserve((size_t)m * nstream * S.halfN * sizeof(uint16_t)));
+            MRC_HIP(h, B.table.reserve((size_t)m * nstream * sizeof(int32_t)));
+            if (g == 4)
+                MRC_TRY(encode_phase_a(h, S, m, C.flushPcm.p, nullptr, sample_format, 2 * (int64_t)L, nullptr, B.lines.as<double>(),
+                                       B.oscale.as<int32_t>(), nullptr, B.smr.as<double>(), B.peak.as<double>(), st, false));
+            else
+                MRC_TRY(encode_phase_a(h, S, m, pcm_left, pcm_right, sample_format, 0, B.offsets.as<int64_t>(),
+                                       B.lines.as<double>(), B.oscale.as<int32_t>(), B.ms.as<int32_t>(), B.smr.as<double>(),
+                                       B.peak.as<double>(), st, false));
+            MRC_HIP(h, launch_chain_prep(S, joint, m, B.lines.as<double>(), B.oscale.as<int32_t>(), B.smr.as<double>(),
+                                         B.peak.as<double>(), joint ? B.ms.as<int32_t>() : nullptr, B.xsel.as<double>(),
+                                         B.peakSel.as<double>(), B.ev.as<unsigned>(), B.pre.as<unsigned>(),
+                                         B.pos.as<unsigned short>(), h->chainForceFallback ? 1 : 0, st));
+        }
+        ChainGroupDev& D = desc[g];
+        D.joint = joint; D.nb = S.nBands; D.nTot = nTot; D.M = S.halfN; D.K = S.maxMantBits - 1; D.nEv = nEv;
+        D.nScaleBits = S.nScaleBits; D.nstream = nstream;
+        D.maxN = 0;
+        for (int v : hs[g]->bandN) if (v > D.maxN) D.maxN = v;
+        D.budgetMono = S.budgetMono; D.budgetJointPre = S.budgetJointPre; D.blkswA = S.blkswA; D.blkswB = S.blkswB;
+        D.bandOfLine = S.bandOfLine; D.bandN = S.bandN;
+        D.xsel = B.xsel.as<double>(); D.peakSel = B.peakSel.as<double>(); D.ev = B.ev.as<unsigned>();
+        D.pre = B.pre.as<unsigned>(); D.pos = B.pos.as<unsigned short>();
+        D.bitAlloc = B.bitAlloc.as<int32_t>(); D.scaleFactor = B.scaleFactor.as<int32_t>();
+        D.mant = B.mant.as<unsigned short>(); D.table = B.table.as<int32_t>();
+    }
+    MRC_HIP(h, C.groupDesc.reserve(sizeof(desc)));
+    MRC_HIP(h, hipMemcpyAsync(C.groupDesc.p, desc, sizeof(desc), hipMemcpyHostToDevice, st));
+    MRC_HIP(h, hipEventRecord(C.evT[1], st));
+    // ---- phase B: the serial scan per stream
+    MRC_HIP(h, launch_chain_phase_b(n_streams, C.groupDesc.as<ChainGroupDev>(), C.items.as<int>(), C.itemStart.as<long long>(),
+                                    C.reservoir.as<int>(), reservoir_trace ? C.resTrace.as<int>() : nullptr,
+                                    use_huffman ? 1 : 0, st));
+    MRC_HIP(h, hipEventRecord(C.evT[2], st));
+    // ---- pack: plan per shape, ONE prefix sum over the chunks in file order, write per shape
+    static const PackTables tables = [] { PackTables t; pack_tables(&t); return t; }();
+    MRC_HIP(h, C.packWs.reserve(pack_workspace_bytes(nChunks)));
+    const PackWs W = pack_ws_views(C.packWs.p, nChunks);
+    MRC_HIP(h, hipMemsetAsync(W.errorFlag, 0, sizeof(int), st));
+    PackParams P[kChainGroups];
+    for (int g = 0; g < nGroups; ++g) {
+        const int joint = g == 4 ? 0 : 1;
+        P[g].nch = joint ? 2 : 1; P[g].joint = joint; P[g].useHuffman = use_huffman ? 1 : 0;
+        P[g].nScaleBits = cfg.n_scale_bits; P[g].nMantSizeBits = cfg.n_mant_size_bits;
+        P[g].blkBitsA = cfg.blksw_bits_a; P[g].blkBitsB = cfg.blksw_bits_b;
+        P[g].bitA = (unsigned)(1 - shapeA[g] / cfg.n_mdct_lines); P[g].bitB = (unsigned)(1 - shapeB[g] / cfg.n_mdct_lines);
+        if (!count[g]) continue;
+        ChainGroupBufs& B = C.g[g];
+        const int64_t nBlk = count[g];                              // (a mono item is a one-channel block)
+        MRC_HIP(h, launch_pack_plan(hs[g]->dev, P[g], tables, nBlk, B.bitAlloc.as<int>(), B.mant.p, MRC_MANTISSA_I16,
+                                    B.table.as<int>(), B.table.as<int>(), nullptr, W, B.chunkMap.as<long long>(),
+                                    all_bands_non_empty(*hs[g]), st));
+    }
+    MRC_HIP(h, launch_pack_scan(nChunks, 0, W, nullptr, num_samples ? C.chunkStream.as<int>() : nullptr, hdrLen, st));
+    for (int g = 0; g < nGroups; ++g) {
+        if (!count[g]) continue;
+        ChainGroupBufs& B = C.g[g];
+        const int bound = (int)(mrc_pack_bound(&cfg, shapeA[g], shapeB[g], 1, P[g].joint) - 4);
+        MRC_HIP(h, launch_pack_write(hs[g]->dev, P[g], tables, count[g], B.oscale.as<int>(), P[g].joint ? B.ms.as<int>() : nullptr,
+                                     B.scaleFactor.as<int>(), B.bitAlloc.as<int>(), B.mant.p, MRC_MANTISSA_I16,
+                                     B.table.as<int>(), W, B.chunkMap.as<long long>(), out, (long long)out_cap, bound,
+                                     all_bands_non_empty(*hs[g]), st));
+    }
+    if (num_samples) {
+        MRC_TRY(upload(h, C.firstChunk, firstChunk, st));
+        MRC_HIP(h, launch_chain_headers(n_streams, hdrLen, C.hdr.as<unsigned char>(), C.firstChunk.as<long long>(), W.pos, out,
+                                        (long long)out_cap, st));
+    }
+    MRC_HIP(h, hipEventRecord(C.evT[3], st));
+    // ---- results: chunk positions, total, error flag, reservoirs
+    MRC_HIP(h, hipMemcpyAsync(pos.data(), W.pos, pos.size() * sizeof(long long), hipMemcpyDeviceToHost, st));
+    MRC_HIP(h, hipMemcpyAsync(&total, W.total, sizeof(total), hipMemcpyDeviceToHost, st));
+    MRC_HIP(h, hipMemcpyAsync(&bad, W.errorFlag, sizeof(bad), hipMemcpyDeviceToHost, st));
+    MRC_HIP(h, hipMemcpyAsync(resOut.data(), C.reservoir.p, resOut.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    if (reservoir_trace)
+        MRC_HIP(h, hipMemcpyAsync(reservoir_trace, C.resTrace.p, (size_t)nItems * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    MRC_HIP(h, hipStreamSynchronize(st));
+    for (int i = 0; i < 3; ++i) {
+        float ms = 0.f;
+        MRC_HIP(h, hipEventElapsedTime(&ms, C.evT[i], C.evT[i + 1]));
+        h->chainMs[i] = ms;
+    }
+    {
+        float ms = 0.f;
+        MRC_HIP(h, hipEventElapsedTime(&ms, C.evT[0], C.evT[3]));
+        h->chainMs[3] = ms;
+    }
+    *total_bytes = total;
+    for (int64_t s = 0; s < n_streams; ++s) stream_byte_offset[s] = pos[(size_t)firstChunk[(size_t)s]] - hdrLen;
+    stream_byte_offset[n_streams] = total;
+    if (item_byte_offset) {
+        for (int64_t i = 0; i < nItems; ++i) item_byte_offset[i] = pos[(size_t)itemChunk[(size_t)i]];
+        item_byte_offset[nItems] = total;
+    }
+    if (reservoir_out) std::memcpy(reservoir_out, resOut.data(), resOut.size() * sizeof(int32_t));
+    if (bad & 3) return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: internal error (table id / chunk size out of range)");
+    if (total > out_cap || (bad & 4)) return fail(h, MRC_ERR_NOMEM, "mrc_encode_chained: out_cap too small (see total_bytes)");
+    return MRC_OK;
+}
+
+int mrc_encode_chained_stream_pac(mrc_handle* h, int64_t n_streams, const void* pcm_left, const void* pcm_right,
+                                  int sample_format, int64_t stream_stride, const int64_t* block_start,
+                                  const int64_t* block_offset, const int32_t* block_a, const int32_t* block_b,
+                                  const int32_t* reservoir_in, int use_huffman, int with_flush, const uint32_t* num_samples,
+                                  uint8_t* out, int64_t out_cap, int64_t* stream_byte_offset, int64_t* item_byte_offset,
+                                  int32_t* reservoir_out, int32_t* reservoir_trace, int64_t* total_bytes) {
+    if (!h || n_streams < 0 || !pcm_left || !pcm_right || stream_stride <= 0 || !out || !total_bytes || !block_start ||
+        (sample_format != MRC_SAMPLES_F64 && sample_format != MRC_SAMPLES_PCM16))
+        return fail(h, MRC_ERR_INVALID, "mrc_encode_chained_stream_pac: bad argument");
+    MRC_HIP(h, hipSetDevice(h->device));
+    ChainBufs& C = h->chain;
+    const int64_t bound = mrc_chain_out_bound(h, n_streams, block_start, block_a, block_b, with_flush, num_samples != nullptr);
+    if (bound < 0) return fail(h, MRC_ERR_INVALID, "mrc_encode_chained_stream_pac: block shape out of range");
+    const size_t pcmBytes = (size_t)n_streams * stream_stride * (sample_format == MRC_SAMPLES_PCM16 ? sizeof(int16_t) : sizeof(double));
+    MRC_HIP(h, C.pcmL.reserve(pcmBytes ? pcmBytes : 1));
+    MRC_HIP(h, C.pcmR.reserve(pcmBytes ? pcmBytes : 1));
+    MRC_HIP(h, C.out.reserve((size_t)bound + 1));
+    SyncGuard guard{h->stream};
+    if (pcmBytes) {
+        MRC_HIP(h, hipMemcpyAsync(C.pcmL.p, pcm_left, pcmBytes, hipMemcpyHostToDevice, h->stream));
+        MRC_HIP(h, hipMemcpyAsync(C.pcmR.p, pcm_right, pcmBytes, hipMemcpyHostToDevice, h->stream));
+    }
+    // the device buffer holds the worst case; the caller's only has to hold what the streams really pack to
+    int rc = mrc_dev_encode_chained_pac(h, n_streams, C.pcmL.p, C.pcmR.p, sample_format, stream_stride, block_start,
+                                        block_offset, block_a, block_b, reservoir_in, use_huffman, with_flush, num_samples,
+                                        C.out.as<uint8_t>(), bound, stream_byte_offset, item_byte_offset, reservoir_out,
+                                        reservoir_trace, total_bytes, h->stream);
+    if (rc != MRC_OK) return rc;
+    if (*total_bytes > out_cap) return fail(h, MRC_ERR_NOMEM, "mrc_encode_chained_stream_pac: out_cap too small (see total_bytes)");
+    if (*total_bytes) MRC_HIP(h, hipMemcpyAsync(out, C.out.p, (size_t)*total_bytes, hipMemcpyDeviceToHost, h->stream));
+    MRC_HIP(h, hipStreamSynchronize(h->stream));
+    return MRC_OK;
+}
+
+int mrc_encode_chained_stream_pcm16_pac(mrc_handle* h, int64_t n_streams, const int16_t* pcm_left, const int16_t* pcm_right,
+                                        int64_t stream_stride, const int64_t* block_start, const int64_t* block_offset,
+                                        const int32_t* block_a, const int32_t* block_b, const int32_t* reservoir_in,
+                                        int use_huffman, int with_flush, const uint32_t* num_samples, uint8_t* out,
+                                        int64_t out_cap, int64_t* stream_byte_offset, int64_t* item_byte_offset,
+                                        int32_t* reservoir_out, int32_t* reservoir_trace, int64_t* total_bytes) {
+    return mrc_encode_chained_stream_pac(h, n_streams, pcm_left, pcm_right, MRC_SAMPLES_PCM16, stream_stride, block_start,
+                                         block_offset, block_a, block_b, reservoir_in, use_huffman, with_flush, num_samples,
+                                         out, out_cap, stream_byte_offset, item_byte_offset, reservoir_out, reservoir_trace,
+                                         total_bytes);
+}
+
+}  // extern "C"

@@ -123,10 +123,54 @@ hipError_t launch_pack(const DevShape& S, const PackParams& P, const PackTables&
                        long long outCap, long long* blockOffset /* [nBlocks + 1] */, void* ws /* pack_workspace_bytes */,
                        int boundBytes /* largest chunk payload */, bool allBandsNonEmpty /* of this shape's table */,
                        hipStream_t st);
+// The three steps of launch_pack on their own, for chunks that several shape groups contribute to ONE output in a
+// given order (the chained stream encode): chunkMap [nBlocks * nch] (nullable) = where each of this group's chunks sits
+// in the global chunk order; chunkBytes / pos are indexed by that global index.  chunkStream (nullable) [nChunks]:
+// the stream each global chunk belongs to -- every stream's first chunk is preceded by a header of hdrLen bytes.
+struct PackWs {                      // views into a workspace of pack_workspace_bytes(nChunks)
+    long long* pos; long long* tileSum; long long* total; int* errorFlag; int* chunkBytes;
+};
+PackWs pack_ws_views(void* ws, int64_t nChunks);
+hipError_t launch_pack_plan(const DevShape& S, const PackParams& P, const PackTables& T, int64_t nBlocks,
+                            const int* bitAlloc, const void* mant, int mantFmt, const int* tableIn, int* tableOut,
+                            int* bitsSaved, const PackWs& W, const long long* chunkMap, bool allBandsNonEmpty,
+                            hipStream_t st);
+hipError_t launch_pack_scan(int64_t nChunks, int nch /* 0: no block offsets */, const PackWs& W, long long* blockOffset,
+                            const int* chunkStream, int hdrLen, hipStream_t st);
+hipError_t launch_pack_write(const DevShape& S, const PackParams& P, const PackTables& T, int64_t nBlocks,
+                             const int* oscale, const int* msSwitch, const int* scaleFactor, const int* bitAlloc,
+                             const void* mant, int mantFmt, const int* table, const PackWs& W, const long long* chunkMap,
+                             unsigned char* out, long long outCap, int boundBytes, bool allBandsNonEmpty, hipStream_t st);
 hipError_t launch_pack_export(const void* ws, int64_t nChunks, long long* hostOut /* page-locked: {total, error flag} */,
                               hipStream_t st);
 const int* pack_error_flag(const void* ws, int64_t nChunks);          // device addresses inside ws
 const long long* pack_total_bytes(const void* ws, int64_t nChunks);
+// mrc_kernels_chain.hip -- chained stream encode: reservoir-free preparation per block, serial scan per stream
+struct ChainGroupDev {               // what chain_phase_b_kernel knows about one block-shape group (device memory)
+    int joint, nb, nTot, M, K, nEv, maxN, nScaleBits, nstream, pad_;
+    double budgetMono, budgetJointPre, blkswA, blkswB;          // codecThem.py:299-308, 381-396
+    const unsigned char* bandOfLine;
+    const int* bandN;
+    const double* xsel;              // [n][nstream][M] lines of the coded streams, scaled by their overall scale
+    const double* peakSel;           // [n][nTot] per-band max |scaled line|
+    const unsigned* ev;              // [n][nEv] grant events in np.argmax's order: band | bitsAfter << 6 | nLines << 11
+    const unsigned* pre;             // [n][nEv + 1] bits spent before each event if all before it are granted
+    const unsigned short* pos;       // [n][nTot][K] where each band's k-th grant sits in ev
+    int* bitAlloc;                   // [n][nstream][nb]
+    int* scaleFactor;                // [n][nstream][nb]
+    unsigned short* mant;            // [n][nstream][M]
+    int* table;                      // [n][nstream] Huffman table id (15 = raw)
+};
+size_t chain_events_per_block(const DevShape& S, int joint);
+hipError_t launch_chain_prep(const DevShape& S, int joint, int64_t nBlocks, const double* lines, const int* oscale,
+                             const double* smr, const double* peak, const int* msSwitch, double* xsel, double* peakSel,
+                             unsigned* ev, unsigned* pre, unsigned short* pos, int forceFallback, hipStream_t st);
+hipError_t launch_chain_phase_b(int64_t nStreams, const ChainGroupDev* groups, const int* items, const long long* itemStart,
+                                int* reservoir, int* resTrace, int useHuffman, hipStream_t st);
+hipError_t launch_chain_flush_gather(int64_t nStreams, int L, const void* pcmL, const void* pcmR, int fmt, int64_t stride,
+                                     const long long* tailOffset, void* out, hipStream_t st);
+hipError_t launch_chain_headers(int64_t nStreams, int hdrLen, const unsigned char* hdr, const long long* firstChunk,
+                                const long long* pos, unsigned char* out, long long outCap, hipStream_t st);
 // mrc_kernels_huff.hip
 hipError_t launch_huffman_gain(const DevShape& S, int64_t nFrames, int nStreams, const int* bitAlloc,
                                const int* mantissa, const int* reservoirOut, int* huffTable, int* bitsSaved,

@@ -70,7 +70,8 @@ template <class MantT>
 __global__ __launch_bounds__(kWave * kWavesPerGroup) void pack_plan_kernel(
     DevShape S, PackParams P, PackTables T, int64_t nChunks, const int* __restrict__ bitAlloc,
     const MantT* __restrict__ mant, const int* __restrict__ tableIn, int* __restrict__ tableOut,
-    int* __restrict__ bitsSaved, int* __restrict__ chunkBytes, int* __restrict__ errorFlag, int fast16) {
+    int* __restrict__ bitsSaved, int* __restrict__ chunkBytes, int* __restrict__ errorFlag, int fast16,
+    const long long* __restrict__ chunkMap /* nullable: this group's chunk -> global chunk index */) {
     __shared__ unsigned sEmit[4 * (kPackLutSize + 1)];
     __shared__ int sBa[kWavesPerGroup * kMaxBands];
     for (int i = threadIdx.x; i < 4 * (kPackLutSize + 1); i += blockDim.x) sEmit[i] = T.emit[i];
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup) void pack_plan_kernel(
     if (P.joint) { if (ch == 0) bits += nb + 4 * P.nScaleBits; }      // pacfileThem.py:826-833
     else bits += P.nScaleBits;                                       // pacfileThem.py:655
     if (lane == 0) {
-        chunkBytes[c] = (bits + 7) / 8;                              // pacfileThem.py:706-707
+        chunkBytes[chunkMap ? chunkMap[c] : c] = (bits + 7) / 8;     // pacfileThem.py:706-707
         tableOut[c] = table;
         if (bitsSaved) bitsSaved[c] = saved;
     }
@@ -181,7 +182,8 @@ __global__ void pack_scan_tiles_kernel(int nTiles, long long* __restrict__ tileS
 __global__ __launch_bounds__(256) void pack_scan_apply_kernel(int64_t n, int nch, const int* __restrict__ chunkBytes,
                                                                const long long* __restrict__ tileSum,
                                                                const long long* __restrict__ total,
-                                                               long long* __restrict__ pos, long long* __restrict__ blockOffset) {
+                                                               long long* __restrict__ pos, long long* __restrict__ blockOffset,
+                                                               const int* __restrict__ chunkStream, int hdrLen) {
     __shared__ int sWave[4];
     const int64_t base = (int64_t)blockIdx.x * kScanTile + 4 * threadIdx.x;
     int v[4], s = 0;
@@ -196,12 +198,21 @@ __global__ __launch_bounds__(256) void pack_scan_apply_kernel(int64_t n, int nch
     for (int j = 0; j < 4; ++j) {
         const int64_t c = base + j;
         if (c < n) {
-            pos[c] = run;
-            if (c % nch == 0) blockOffset[c / nch] = run;
+            // chunkStream: a file header of hdrLen bytes precedes the first chunk of every stream
+            const long long at = run + (chunkStream ? (long long)hdrLen * (chunkStream[c] + 1) : 0);
+            pos[c] = at;
+            if (nch > 0 && c % nch == 0) blockOffset[c / nch] = at;
         }
         run += v[j];
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) blockOffset[n / nch] = *total;
+    if (nch > 0 && blockIdx.x == 0 && threadIdx.x == 0) blockOffset[n / nch] = *total;
+}
+// (after pack_scan_apply_kernel has read it) the total with the headers in, and the end position behind the last chunk
+__global__ void pack_scan_finish_kernel(int64_t n, long long* __restrict__ total, long long* __restrict__ pos,
+                                        const int* __restrict__ chunkStream, int hdrLen) {
+    if (threadIdx.x || blockIdx.x) return;
+    if (chunkStream && n > 0) *total += (long long)hdrLen * (chunkStream[n - 1] + 1);
+    pos[n] = *total;
 }
 
 // ---- payloads ---------------------------------------------------------------------------------------------------
@@ -219,7 +230,8 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup) void pack_write_kernel(
     const int* __restrict__ msSwitch, const int* __restrict__ scaleFactor, const int* __restrict__ bitAlloc,
     const MantT* __restrict__ mant, const int* __restrict__ table, const int* __restrict__ chunkBytes,
     const long long* __restrict__ pos, unsigned char* __restrict__ out, long long outCap, int wordsPerWave,
-    int fast16 /* 1024 lines, every band non-empty, planes 16-byte aligned */) {
+    int fast16 /* 1024 lines, every band non-empty, planes 16-byte aligned */,
+    const long long* __restrict__ chunkMap, int* __restrict__ errorFlag) {
     extern __shared__ unsigned smem[];
     unsigned* sEmit = smem;                                                     // [4 (kPackLutSize + 1)]
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x >> 6;
@@ -235,9 +247,14 @@ __global__ __launch_bounds__(kWave * kWavesPerGroup) void pack_write_kernel(
     if (c >= nChunks) return;
     const int64_t blk = c / P.nch;
     const int ch = (int)(c % P.nch);
-    const int nBytes = chunkBytes[c];
-    const long long p0 = pos[c];
-    if (p0 + 4 + nBytes > outCap || nBytes > 4 * (wordsPerWave - 1)) return;    // (the caller reports the overflow)
+    const int64_t gc = chunkMap ? chunkMap[c] : c;
+    const int nBytes = chunkBytes[gc];
+    const long long p0 = pos[gc];
+    if (p0 + 4 + nBytes > outCap || nBytes > 4 * (wordsPerWave - 1)) {          // nothing is written: the caller learns why
+        // 2: a chunk larger than mrc_pack_bound allows (bit_alloc > 16 handed in), 4: out_cap exceeded
+        if (lane == 0) atomicOr(errorFlag, nBytes > 4 * (wordsPerWave - 1) ? 2 : 4);
+        return;
+    }
     const int tbl = table[c];
     const int* ba = bitAlloc + c * nb;
     const int* sf = scaleFactor + c * nb;
@@ -379,38 +396,75 @@ hipError_t launch_pack_export(const void* ws, int64_t nChunks, long long* hostOu
 
 size_t pack_workspace_bytes(int64_t nChunks) {
     const int64_t nTiles = (nChunks + kScanTile - 1) / kScanTile;
-    return (size_t)nChunks * (sizeof(int) + sizeof(long long)) + (size_t)(nTiles + 2) * sizeof(long long) + 64;
+    return (size_t)(nChunks + 1) * (sizeof(int) + sizeof(long long)) + (size_t)(nTiles + 2) * sizeof(long long) + 64;
 }
 
-template <class MantT>
-static hipError_t launch_pack_t(const DevShape& S, const PackParams& P, const PackTables& T, int64_t nBlocks,
-                                const int* oscale, const int* msSwitch, const int* scaleFactor, const int* bitAlloc,
-                                const MantT* mant, const int* tableIn, int* tableOut, int* bitsSaved, unsigned char* out,
-                                long long outCap, long long* blockOffset, void* ws, int boundBytes, bool packFast16Ok,
-                                hipStream_t st) {
-    const int64_t nChunks = nBlocks * P.nch;
+// workspace: pos [nChunks + 1] | tile sums [nTiles] | total | error flag | chunkBytes [nChunks]
+PackWs pack_ws_views(void* ws, int64_t nChunks) {
     const int64_t nTiles = (nChunks + kScanTile - 1) / kScanTile;
-    // workspace: pos [nChunks] | tile sums [nTiles] | total | error flag | chunkBytes [nChunks]
-    long long* pos = reinterpret_cast<long long*>(ws);
-    long long* tileSum = pos + nChunks;
-    long long* total = tileSum + nTiles;
-    int* errorFlag = reinterpret_cast<int*>(total + 1);
-    int* chunkBytes = errorFlag + 2;
-    (void)hipMemsetAsync(errorFlag, 0, sizeof(int), st);
+    PackWs W;
+    W.pos = reinterpret_cast<long long*>(ws);
+    W.tileSum = W.pos + nChunks + 1;
+    W.total = W.tileSum + nTiles;
+    W.errorFlag = reinterpret_cast<int*>(W.total + 1);
+    W.chunkBytes = W.errorFlag + 2;
+    return W;
+}
+
+static int pack_fast16(const DevShape& S, const void* mant, size_t mantSize, bool packFast16Ok) {
+    return S.halfN == 16 * kWave && S.nBands <= 32 && packFast16Ok && !(reinterpret_cast<uintptr_t>(mant) & 15) &&
+           ((size_t)S.halfN * mantSize) % 16 == 0;
+}
+
+hipError_t launch_pack_plan(const DevShape& S, const PackParams& P, const PackTables& T, int64_t nBlocks,
+                            const int* bitAlloc, const void* mant, int mantFmt, const int* tableIn, int* tableOut,
+                            int* bitsSaved, const PackWs& W, const long long* chunkMap, bool allBandsNonEmpty,
+                            hipStream_t st) {
+    const int64_t nChunks = nBlocks * P.nch;
+    if (nChunks <= 0) return hipSuccess;
     const unsigned groups = (unsigned)((nChunks + kWavesPerGroup - 1) / kWavesPerGroup);
-    const int fast16 = S.halfN == 16 * kWave && S.nBands <= 32 && packFast16Ok &&
-                       !(reinterpret_cast<uintptr_t>(mant) & 15) && ((size_t)S.halfN * sizeof(MantT)) % 16 == 0;
-    hipLaunchKernelGGL((pack_plan_kernel<MantT>), dim3(groups), dim3(kWave * kWavesPerGroup), 0, st, S, P, T, nChunks,
-                       bitAlloc, mant, tableIn, tableOut, bitsSaved, chunkBytes, errorFlag, fast16);
-    hipLaunchKernelGGL(pack_scan_sums_kernel, dim3((unsigned)nTiles), dim3(256), 0, st, nChunks, chunkBytes, tileSum);
-    hipLaunchKernelGGL(pack_scan_tiles_kernel, dim3(1), dim3(64), 0, st, (int)nTiles, tileSum, total);
-    hipLaunchKernelGGL(pack_scan_apply_kernel, dim3((unsigned)nTiles), dim3(256), 0, st, nChunks, P.nch, chunkBytes,
-                       tileSum, total, pos, blockOffset);
+    if (mantFmt == MRC_MANTISSA_I16)
+        hipLaunchKernelGGL((pack_plan_kernel<unsigned short>), dim3(groups), dim3(kWave * kWavesPerGroup), 0, st, S, P, T,
+                           nChunks, bitAlloc, (const unsigned short*)mant, tableIn, tableOut, bitsSaved, W.chunkBytes,
+                           W.errorFlag, pack_fast16(S, mant, 2, allBandsNonEmpty), chunkMap);
+    else
+        hipLaunchKernelGGL((pack_plan_kernel<int>), dim3(groups), dim3(kWave * kWavesPerGroup), 0, st, S, P, T, nChunks,
+                           bitAlloc, (const int*)mant, tableIn, tableOut, bitsSaved, W.chunkBytes, W.errorFlag,
+                           pack_fast16(S, mant, 4, allBandsNonEmpty), chunkMap);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_scan(int64_t nChunks, int nch, const PackWs& W, long long* blockOffset, const int* chunkStream,
+                            int hdrLen, hipStream_t st) {
+    if (nChunks <= 0) return hipSuccess;
+    const int64_t nTiles = (nChunks + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(pack_scan_sums_kernel, dim3((unsigned)nTiles), dim3(256), 0, st, nChunks, W.chunkBytes, W.tileSum);
+    hipLaunchKernelGGL(pack_scan_tiles_kernel, dim3(1), dim3(64), 0, st, (int)nTiles, W.tileSum, W.total);
+    hipLaunchKernelGGL(pack_scan_apply_kernel, dim3((unsigned)nTiles), dim3(256), 0, st, nChunks, nch, W.chunkBytes,
+                       W.tileSum, W.total, W.pos, blockOffset, chunkStream, hdrLen);
+    hipLaunchKernelGGL(pack_scan_finish_kernel, dim3(1), dim3(64), 0, st, nChunks, W.total, W.pos, chunkStream, hdrLen);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_write(const DevShape& S, const PackParams& P, const PackTables& T, int64_t nBlocks,
+                             const int* oscale, const int* msSwitch, const int* scaleFactor, const int* bitAlloc,
+                             const void* mant, int mantFmt, const int* table, const PackWs& W, const long long* chunkMap,
+                             unsigned char* out, long long outCap, int boundBytes, bool allBandsNonEmpty, hipStream_t st) {
+    const int64_t nChunks = nBlocks * P.nch;
+    if (nChunks <= 0) return hipSuccess;
+    const unsigned groups = (unsigned)((nChunks + kWavesPerGroup - 1) / kWavesPerGroup);
     const int wordsPerWave = (boundBytes + 3) / 4 + 2;
     const int prefLen = (S.halfN + (S.halfN >> 4)) + 2;
     const size_t lds = sizeof(unsigned) * (4 * (kPackLutSize + 1) + (size_t)kWavesPerGroup * (wordsPerWave + prefLen + kWave));
-    hipLaunchKernelGGL((pack_write_kernel<MantT>), dim3(groups), dim3(kWave * kWavesPerGroup), lds, st, S, P, T, nChunks,
-                       oscale, msSwitch, scaleFactor, bitAlloc, mant, tableOut, chunkBytes, pos, out, outCap, wordsPerWave, fast16);
+    if (mantFmt == MRC_MANTISSA_I16)
+        hipLaunchKernelGGL((pack_write_kernel<unsigned short>), dim3(groups), dim3(kWave * kWavesPerGroup), lds, st, S, P,
+                           T, nChunks, oscale, msSwitch, scaleFactor, bitAlloc, (const unsigned short*)mant, table,
+                           W.chunkBytes, W.pos, out, outCap, wordsPerWave, pack_fast16(S, mant, 2, allBandsNonEmpty),
+                           chunkMap, W.errorFlag);
+    else
+        hipLaunchKernelGGL((pack_write_kernel<int>), dim3(groups), dim3(kWave * kWavesPerGroup), lds, st, S, P, T, nChunks,
+                           oscale, msSwitch, scaleFactor, bitAlloc, (const int*)mant, table, W.chunkBytes, W.pos, out,
+                           outCap, wordsPerWave, pack_fast16(S, mant, 4, allBandsNonEmpty), chunkMap, W.errorFlag);
     return hipGetLastError();
 }
 
@@ -419,20 +473,18 @@ hipError_t launch_pack(const DevShape& S, const PackParams& P, const PackTables&
                        const int* tableIn, int* tableOut, int* bitsSaved, unsigned char* out, long long outCap,
                        long long* blockOffset, void* ws, int boundBytes, bool allBandsNonEmpty, hipStream_t st) {
     if (nBlocks <= 0) return hipSuccess;
-    if (mantFmt == MRC_MANTISSA_I16)
-        return launch_pack_t(S, P, T, nBlocks, oscale, msSwitch, scaleFactor, bitAlloc, (const unsigned short*)mant, tableIn,
-                             tableOut, bitsSaved, out, outCap, blockOffset, ws, boundBytes, allBandsNonEmpty, st);
-    return launch_pack_t(S, P, T, nBlocks, oscale, msSwitch, scaleFactor, bitAlloc, (const int*)mant, tableIn, tableOut,
-                         bitsSaved, out, outCap, blockOffset, ws, boundBytes, allBandsNonEmpty, st);
+    const int64_t nChunks = nBlocks * P.nch;
+    const PackWs W = pack_ws_views(ws, nChunks);
+    (void)hipMemsetAsync(W.errorFlag, 0, sizeof(int), st);
+    hipError_t e = launch_pack_plan(S, P, T, nBlocks, bitAlloc, mant, mantFmt, tableIn, tableOut, bitsSaved, W, nullptr,
+                                    allBandsNonEmpty, st);
+    if (e != hipSuccess) return e;
+    if ((e = launch_pack_scan(nChunks, P.nch, W, blockOffset, nullptr, 0, st)) != hipSuccess) return e;
+    return launch_pack_write(S, P, T, nBlocks, oscale, msSwitch, scaleFactor, bitAlloc, mant, mantFmt, tableOut, W, nullptr,
+                             out, outCap, boundBytes, allBandsNonEmpty, st);
 }
 
-const int* pack_error_flag(const void* ws, int64_t nChunks) {
-    const int64_t nTiles = (nChunks + kScanTile - 1) / kScanTile;
-    return reinterpret_cast<const int*>(reinterpret_cast<const long long*>(ws) + nChunks + nTiles + 1);
-}
-const long long* pack_total_bytes(const void* ws, int64_t nChunks) {
-    const int64_t nTiles = (nChunks + kScanTile - 1) / kScanTile;
-    return reinterpret_cast<const long long*>(ws) + nChunks + nTiles;
-}
+const int* pack_error_flag(const void* ws, int64_t nChunks) { return pack_ws_views(const_cast<void*>(ws), nChunks).errorFlag; }
+const long long* pack_total_bytes(const void* ws, int64_t nChunks) { return pack_ws_views(const_cast<void*>(ws), nChunks).total; }
 
 }  // namespace mrc

@@ -345,8 +345,8 @@ int64_t mrc_pack_bound(const mrc_config* cfg, int a, int b, int n_channels, int 
     if (!mrc::band_table(*cfg, a, b, &cnt)) return MRC_ERR_INVALID;
     // worst case per line: 16 raw bits + the longest escape code (6 bits); header fields on top
     const int64_t half = (a + b) / 2;
-    int64_t bits = 4 + 2 + 4 * cfg->n_scale_bits + (int64_t)cnt.size() * (1 + cfg->n_mant_size_bits + cfg->n_scale_bits) +
-                   half * (16 + 9);
+    int64_t bits = 4 + cfg->blksw_bits_a + cfg->blksw_bits_b + 4 * cfg->n_scale_bits +
+                   (int64_t)cnt.size() * (1 + cfg->n_mant_size_bits + cfg->n_scale_bits) + half * (16 + 9);
     (void)joint;
     return (int64_t)n_channels * (4 + (bits + 7) / 8);
 }

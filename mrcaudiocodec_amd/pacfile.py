@@ -112,11 +112,44 @@ def pack_joint_blocks(cfg, a, b, overall_scale, ms_switch, scale_factor, bit_all
 
 
 def encode_stereo_stream(handle, stream, shapes, use_huffman=True, num_samples=None):
-    """The encode half of the reference CLI for a stereo stream [2][samples] that starts with the zero
-    prior hop and a given block-shape sequence [(offset, a, b)]: header, one joint block per shape with the
-    bit reservoir chained through the Huffman savings (codecThem.py:274,503), then Close()'s flush block
-    through the non-joint writer (pacfileThem.py:973-984).  Kernels on the GPU of `handle`, Huffman + bit
-    packing in C++ on the host.  Returns the .pac bytes."""
+    """The encode half of the reference CLI for ONE stereo stream [2][samples] (float64 signed fractions or int16 PCM
+    codes) that starts with the zero prior hop and a given block-shape sequence [(offset, a, b)]: header, one joint block
+    per shape with the bit reservoir chained through the Huffman savings (codecThem.py:274,503), then Close()'s flush
+    block through the non-joint writer (pacfileThem.py:973-984).  One library call (mrc_encode_chained_stream_pac): the
+    reservoir-free 95 % of the work runs as a batch over all blocks, the rest as a serial scan on the device, the
+    packer on the device too.  Returns the .pac bytes."""
+    stream = np.asarray(stream)
+    return encode_stereo_streams(handle, stream[None], [shapes], use_huffman,
+                                 None if num_samples is None else [num_samples])[0]
+
+
+def encode_stereo_streams(handle, streams, shapes, use_huffman=True, num_samples=None):
+    """encode_stereo_stream for MANY stereo streams at once: streams [nStreams][2][samples], shapes[s] = block-shape
+    sequence of stream s, num_samples[s] (optional) = the header's sample count (default: the samples the blocks
+    cover).  Returns a list of .pac byte strings, each identical to what the reference's driver writes for that
+    stream alone."""
+    L = handle.cfg.n_mdct_lines
+    streams = np.asarray(streams)
+    if streams.dtype != np.int16:
+        streams = streams.astype(np.float64, copy=False)
+    nS = streams.shape[0]
+    if streams.ndim != 3 or streams.shape[1] != 2 or len(shapes) != nS:
+        raise ValueError("streams [nStreams][2][samples] and one shape list per stream expected")
+    for sh in shapes:
+        if not len(sh) or sh[-1][2] != L:
+            raise ValueError("every stream must end with a long block (the reference's Close() assumes it)")
+    if num_samples is None:
+        num_samples = [sum(int(b) for (_, _, b) in sh) for sh in shapes]       # the CLI writes the WAV's count
+    r = handle.encode_chained_pac(streams[:, 0], streams[:, 1], shapes, use_huffman=use_huffman, with_flush=True,
+                                  num_samples=num_samples)
+    data, offs = r["bytes"], r["stream_offset"]
+    return [data[offs[s]:offs[s + 1]].tobytes() for s in range(nS)]
+
+
+def encode_stereo_stream_per_block(handle, stream, shapes, use_huffman=True, num_samples=None):
+    """The block-at-a-time form of encode_stereo_stream, as the reference's loop runs it (and as this package ran it
+    before the chained call existed): one mrc_encode_joint per block, the reservoir carried on the host, C++ packer.
+    Kept as the cross-check of the chained path (same bytes) and as the 'before' of its speed-up."""
     c = handle.cfg
     cfg = make_config(c.sample_rate, c.n_mdct_lines, c.n_short, c.n_scale_bits, c.n_mant_size_bits,
                       c.target_bits_per_sample, c.blksw_bits_a, c.blksw_bits_b)
@@ -142,63 +175,6 @@ def encode_stereo_stream(handle, stream, shapes, use_huffman=True, num_samples=N
         reservoir = int(r["reservoir_out"][0]) + int(saved.sum())
         out.append(data.tobytes())
     return b"".join(out)
-
-
-def encode_stereo_streams(handle, streams, shapes, use_huffman=True, num_samples=None):
-    """encode_stereo_stream for MANY stereo streams at once (stream mode): streams [nStreams][2][samples],
-    shapes[s] = block-shape sequence of stream s, num_samples[s] (optional) = the header's sample count.
-    All streams advance one block per step on the GPU with their bit reservoirs chained on the device
-    (batch.StreamEncoder.encode_chained: kernels + Huffman pricing, no host round trip per block); the
-    bytes are packed afterwards ON THE DEVICE too (mrc_dev_pack_blocks), one call per (step, block shape).  Returns a list
-    of .pac byte strings, each identical to what encode_stereo_stream gives for that stream alone."""
-    import torch
-    from .batch import StreamEncoder
-    c = handle.cfg
-    cfg = make_config(c.sample_rate, c.n_mdct_lines, c.n_short, c.n_scale_bits, c.n_mant_size_bits,
-                      c.target_bits_per_sample, c.blksw_bits_a, c.blksw_bits_b)
-    L = c.n_mdct_lines
-    streams = np.asarray(streams, dtype=np.float64)
-    nS = streams.shape[0]
-    if streams.ndim != 3 or streams.shape[1] != 2 or len(shapes) != nS:
-        raise ValueError("streams [nStreams][2][samples] and one shape list per stream expected")
-    for sh in shapes:
-        if not sh or sh[-1][2] != L:
-            raise ValueError("every stream must end with a long block (the reference's Close() assumes it)")
-    enc = StreamEncoder(handle)
-    dev = enc.device
-    left = torch.from_numpy(np.ascontiguousarray(streams[:, 0])).to(dev)
-    right = torch.from_numpy(np.ascontiguousarray(streams[:, 1])).to(dev)
-    steps, reservoir = enc.encode_chained(left, right, shapes, use_huffman)
-
-    # Close(): one more (L, L) block per channel, the last hop followed by zeros, through the non-joint writer
-    flush = torch.zeros((2, nS, 2 * L), dtype=torch.float64, device=dev)
-    tail = torch.tensor([sh[-1][0] + sh[-1][1] for sh in shapes], dtype=torch.int64, device=dev)
-    cols = tail[:, None] + torch.arange(L, device=dev)[None, :]
-    flush[0, :, :L] = torch.gather(left, 1, cols)
-    flush[1, :, :L] = torch.gather(right, 1, cols)
-    closing = []
-    for ch in range(2):
-        out = enc.encode(L, L, flush[ch].reshape(-1), None, nS, 2 * L, None, reservoir.contiguous(), fresh=True)
-        out["huff_table"], _, reservoir = enc.huffman_gain(L, L, out, use_huffman)
-        closing.append(out)
-    torch.cuda.synchronize(dev)
-
-    parts = [[header(cfg, 2, sum(b for (_, _, b) in sh) if num_samples is None else num_samples[s])]
-             for s, sh in enumerate(shapes)]
-    # the table of every chunk was chosen on the device (huffman_gain_kernel); recoding and bit packing happen there too
-    # (mrc_dev_pack_blocks): only the packed bytes and their offsets come back, the host cuts them per stream
-    def packed(a, b, out):
-        r = enc.pack(a, b, out, use_huffman=use_huffman, huff_table=out["huff_table"].contiguous())
-        return r["bytes"].cpu().numpy(), r["block_offset"].cpu().numpy()
-    for ids, a, b, out in steps:
-        data, offs = packed(a, b, out)
-        for i, s in enumerate(ids):
-            parts[s].append(data[offs[i]:offs[i + 1]].tobytes())
-    for out in closing:
-        data, offs = packed(L, L, out)
-        for s in range(nS):
-            parts[s].append(data[offs[s]:offs[s + 1]].tobytes())
-    return [b"".join(p) for p in parts]
 
 
 # ------------------------------------------------------------------ decode side ("next" row f-4)

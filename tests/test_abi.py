@@ -30,7 +30,7 @@ def test_library_exports_every_header_symbol():
     for n in names:
         assert hasattr(raw, n), "libmrc_hip.so does not export %s" % n
         assert n in _lib.EXPORTS, "ctypes binding does not declare %s" % n
-    assert _lib.lib.mrc_version() == 200
+    assert _lib.lib.mrc_version() == 300
 
 
 def test_no_cpu_fallback_without_gpu():
