@@ -428,6 +428,9 @@ int mrc_set_timing(mrc_handle* h, int enabled);
 /* MRC_OPT_CHAIN_FORCE_REPAIR = 1 (tests only): the chained encode's event preparation scrambles its candidate order so
  * that the repair pass, which otherwise only runs on near-ties that rounding turned round, does real work. */
 #define MRC_OPT_CHAIN_FORCE_REPAIR 3
+/* MRC_OPT_CHAIN_THREADS = 0 | 256 | 512 | 1024: threads of the workgroup that walks one stream in the chained encode's
+ * serial scan (default 0: 512 for up to 512 streams -- the latency of the one stream counts -- else 256: eight streams per CU). */
+#define MRC_OPT_CHAIN_THREADS 4
 int mrc_set_option(mrc_handle* h, int option, int value);
 int mrc_get_stage_ms(mrc_handle* h, double* ms /*[3]*/);
 /* ... and per kernel: ms[0..4] = MDCT, smr_kernel, band_stats_kernel (joint only, else ~0), bitalloc_kernel,

@@ -150,6 +150,11 @@ int mrc_set_option(mrc_handle* h, int option, int value) {
     if (option == MRC_OPT_EXACT_SPREAD) { h->exactSpread = value != 0; return MRC_OK; }
     if (option == MRC_OPT_SMR_ALL_BANDS) { h->smrAllBands = value != 0; return MRC_OK; }
     if (option == MRC_OPT_CHAIN_FORCE_REPAIR) { h->chainForceFallback = value != 0; return MRC_OK; }
+    if (option == MRC_OPT_CHAIN_THREADS) {
+        if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(h, MRC_ERR_INVALID, "mrc_set_option: MRC_OPT_CHAIN_THREADS takes 0, 256, 512 or 1024");
+        h->chainThreads = value;
+        return MRC_OK;
+    }
     return fail(h, MRC_ERR_INVALID, "mrc_set_option: unknown option");
 }
 

@@ -233,7 +233,7 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
     // ---- phase B: the serial scan per stream
     MRC_HIP(h, launch_chain_phase_b(n_streams, C.groupDesc.as<ChainGroupDev>(), C.items.as<int>(), C.itemStart.as<long long>(),
                                     C.reservoir.as<int>(), reservoir_trace ? C.resTrace.as<int>() : nullptr,
-                                    use_huffman ? 1 : 0, st));
+                                    use_huffman ? 1 : 0, h->chainThreads, st));
     MRC_HIP(h, hipEventRecord(C.evT[2], st));
     // ---- pack: plan per shape, ONE prefix sum over the chunks in file order, write per shape
     static const PackTables tables = [] { PackTables t; pack_tables(&t); return t; }();

@@ -104,6 +104,7 @@ struct mrc_handle {
     bool timing = false;
     bool exactSpread = false;        // mrc_set_option(MRC_OPT_EXACT_SPREAD)
     bool smrAllBands = false;        // mrc_set_option(MRC_OPT_SMR_ALL_BANDS)
+    int chainThreads = 0;            // mrc_set_option(MRC_OPT_CHAIN_THREADS): workgroup size of the serial scan, 0 = by stream count
     bool chainForceFallback = false; // mrc_set_option(MRC_OPT_CHAIN_FORCE_REPAIR): tests of chain_prep_kernel's repair pass
     hipEvent_t ev[mrc::kKernelEvents] = {};
     double stageMs[3] = {0, 0, 0};

@@ -155,7 +155,7 @@ struct ChainGroupDev {               // what chain_phase_b_kernel knows about on
     const double* peakSel;           // [n][nTot] per-band max |scaled line|
     const unsigned* ev;              // [n][nEv] grant events in np.argmax's order: band | bitsAfter << 6 | nLines << 11
     const unsigned* pre;             // [n][nEv + 1] bits spent before each event if all before it are granted
-    const unsigned short* pos;       // [n][nTot][K] where each band's k-th grant sits in ev
+    const unsigned short* pos;       // [n][K][nTot] where each band's k-th grant sits in ev
     int* bitAlloc;                   // [n][nstream][nb]
     int* scaleFactor;                // [n][nstream][nb]
     unsigned short* mant;            // [n][nstream][M]
@@ -166,7 +166,8 @@ hipError_t launch_chain_prep(const DevShape& S, int joint, int64_t nBlocks, cons
                              const double* smr, const double* peak, const int* msSwitch, double* xsel, double* peakSel,
                              unsigned* ev, unsigned* pre, unsigned short* pos, int forceFallback, hipStream_t st);
 hipError_t launch_chain_phase_b(int64_t nStreams, const ChainGroupDev* groups, const int* items, const long long* itemStart,
-                                int* reservoir, int* resTrace, int useHuffman, hipStream_t st);
+                                int* reservoir, int* resTrace, int useHuffman, int threads /* 0: chosen by stream count */,
+                                hipStream_t st);
 hipError_t launch_chain_flush_gather(int64_t nStreams, int L, const void* pcmL, const void* pcmR, int fmt, int64_t stride,
                                      const long long* tailOffset, void* out, hipStream_t st);
 hipError_t launch_chain_headers(int64_t nStreams, int hdrLen, const unsigned char* hdr, const long long* firstChunk,

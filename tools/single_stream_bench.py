@@ -45,8 +45,10 @@ def main():
     ap.add_argument("--loop-blocks", type=int, default=256)
     ap.add_argument("--period", type=int, default=37)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--threads", type=int, default=0, help="MRC_OPT_CHAIN_THREADS (0: the library's choice)")
     a = ap.parse_args()
     h = Handle(device_id=0)
+    h.set_option(4, a.threads)
     pcm = make_stream(a.hops, a.period)
     x = synth.pcm_to_float(pcm)
     t0 = time.perf_counter()
