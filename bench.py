@@ -24,11 +24,15 @@ Extra objects on the line:
   kernels       the same for every kernel of the path.
   host_to_host  N = 1: PCM in page-locked host memory -> codes in page-locked host memory (H2D + kernels + D2H,
                 mrc_encode_stream_pcm16, chunks pipelined over 3 HIP streams), median of >= 5 runs.
-  configs       N = 1: configs[2] (stereo, joint M/S path) and configs[3] (block switching long/short) resident
-                rates with their own roofline objects.
-  configs4      N > 1: BASELINE.json configs[4] -- the C3 stereo content as ONE stream of world * F' frames, frame-
-                sharded with halo, joint path; whole-job Msamples/s over the max-over-ranks time, and the host
-                Huffman + bit-packing rate of the ranks' outputs (`host_pack_Msamples_s`, reported separately).
+  configs       N = 1: configs[2] (stereo, joint M/S path) and configs[3] (block switching long/short, block shapes from
+                the transient detector on the content, its kernel inside the timed step) resident rates with their own
+                roofline objects; stream_mode (many stereo streams, reservoirs chained) and single_stream (ONE long
+                stereo stream -> one .pac file) through the chained call (mrc_*_encode_chained_pac).
+  configs4      N > 1: BASELINE.json configs[4] -- the C3 stereo content as ONE stream of world * F' frames
+                (F' = 10^7 / 8 per GPU: 10^7 frames at N = 8), frame-sharded with halo, joint path; whole-job Msamples/s
+                over the max-over-ranks time, the host Huffman + bit-packing rate of the ranks' outputs
+                (`host_pack_Msamples_s`, reported separately), a per-rank host_to_host leg (every rank its own page-locked
+                buffers, max over ranks: PCIe / NUMA contention shows here) and stream_mode with whole streams per rank.
   cpu_baseline  N = 1: the oracle's faithful NumPy port of the reference path on the host: 1 core, and all cores
                 (one process per core over disjoint frame ranges, core count stated).
 """
@@ -49,8 +53,10 @@ FP64_PEAK_TFLOPS = 78.6         # vector fp64 (= matrix fp64 on MI355X)
 
 
 # ---------------------------------------------------------------------------------------------- algorithmic bytes
-def algorithmic_bytes(joint, pcm16, mant16, a=1024, b=1024, nb=NB):
-    """Per block and kernel.  Long mono block, f64 layout: the figures of SURVEY.md 8(d)."""
+def algorithmic_bytes(joint, pcm16, mant16, a=1024, b=1024, nb=NB, coded_line_frac=1.0):
+    """Per block and kernel.  Long mono block, f64 layout: the figures of SURVEY.md 8(d).
+    coded_line_frac: the share of lines in bands that were given bits -- quantize_kernel does not load the others
+    (their codes are 0 whatever the line holds), so they are not algorithmic bytes of it."""
     half = (a + b) // 2
     smp = 2 if pcm16 else 8
     nsig, nch, nstream = (4, 2, 2) if joint else (1, 1, 1)
@@ -62,9 +68,16 @@ def algorithmic_bytes(joint, pcm16, mant16, a=1024, b=1024, nb=NB):
         "smr": new + nsig * (lines + 4 + 2 * nb * 8),           # lines + overall scale in; SMRs + band peaks out
         "band_stats": (2 * lines + 4 * nb) if joint else 0,     # L, R lines in; M/S switch out
         "bitalloc": nsig * nb * 8 + 4 + (4 * nb if joint else 0) + nstream * 4 * nb + 4,
-        "quantize": nstream * (lines + mant + 4 * nb * 3) + nsig * (4 + 8 * nb),
+        "quantize": nstream * (coded_line_frac * lines + mant + 4 * nb * 3) + nsig * (4 + 8 * nb),
         "path": new + nstream * (mant + 8 * nb) + 4 * nsig + (4 * nb if joint else 0) + 4,
     }
+
+
+def coded_line_fraction(np, out, bands):
+    """share of lines that lie in bands with a non-zero bit allocation (from an encode result)"""
+    ba = out["bit_alloc"].cpu().numpy()
+    w = np.asarray(bands, dtype=np.float64)
+    return float(((ba > 0) * w).sum() / (ba.shape[0] * ba.shape[1] * w.sum()))
 
 
 KERNEL_NAMES = ["mdct", "smr", "band_stats", "bitalloc", "quantize"]
@@ -165,7 +178,31 @@ def stream_slice(torch, device, kind, first_frame, n_frames):
         burst = ((hop % 5) == 4) & ((s - hop * HOP) < 128)
         sigma = torch.where(burst, 0.5 * 32767, 0.01 * 32767)
         return [torch.where(live, to_pcm16(torch, gauss_at(torch, s, 42) * sigma), 0).contiguous()]
+    if kind == "c5":
+        # one long stereo programme: noise floor + a 440 Hz tone, a 128-sample burst every 37th hop (detector food)
+        hop = torch.div(s, HOP, rounding_mode="floor")
+        burst = ((hop % 37) == 36) & ((s - hop * HOP) < 128)
+        g1, g2 = gauss_at(torch, s, 77), gauss_at(torch, s, 78)
+        tone = 0.2 * 32767 * torch.sin(s.to(torch.float64) * (2 * 3.141592653589793 * 440.0 / 48000))
+        l = torch.where(burst, g1 * (0.5 * 32767), g1 * (0.02 * 32767) + tone)
+        r = torch.where(burst, g1 * (0.4 * 32767), (0.7 * g1 + 0.3 * g2) * (0.02 * 32767) + 0.9 * tone)
+        z = torch.zeros((), dtype=torch.int16, device=device)
+        return [torch.where(live, to_pcm16(torch, l), z).contiguous(), torch.where(live, to_pcm16(torch, r), z).contiguous()]
     raise ValueError(kind)
+
+
+def stream_slices(torch, device, kind, first_frame, n_frames, piece=1 << 17):
+    """stream_slice for long ranges: generated piece by piece into preallocated tensors (the generator's float64
+    temporaries are eight times the size of the int16 result)."""
+    nch = 1 if kind in ("c2", "c4") else 2
+    out = [torch.empty(((n_frames + 1) * HOP,), dtype=torch.int16, device=device) for _ in range(nch)]
+    for f0 in range(0, max(n_frames, 1), piece):
+        n = min(piece, n_frames - f0)
+        part = stream_slice(torch, device, kind, first_frame + f0, n)
+        for c in range(nch):
+            out[c][f0 * HOP:(f0 + n + 1) * HOP] = part[c]
+        del part
+    return out
 
 
 def c4_shapes(n_hops):
@@ -262,8 +299,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames", type=int, default=1 << 17, help="mono frames per GPU per step")
-    ap.add_argument("--h2h-frames", type=int, default=0, help="frames of the host-to-host stream (0 = 4 x --frames)")
+    ap.add_argument("--frames", type=int, default=1 << 20, help="mono frames per GPU per step of the headline (SURVEY 8(d) C2: 2^20)")
+    ap.add_argument("--extra-frames", type=int, default=1 << 17, help="frames per step of the other single-GPU configurations")
+    ap.add_argument("--h2h-frames", type=int, default=1 << 19, help="frames of the host-to-host stream")
+    ap.add_argument("--c4-frames", type=int, default=10 ** 7 // 8,
+                    help="N > 1: stereo frames per GPU per step of configs[4] (10^7 / 8: 10^7 frames at N = 8)")
+    ap.add_argument("--single-hops", type=int, default=1 << 16, help="hops of the single-stream configuration")
     ap.add_argument("--cpu-frames", type=int, default=256, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--skip-extras", action="store_true", help="only the headline measurement (profiling runs)")
     ap.add_argument("--only", choices=["stereo", "switch"], default=None,
@@ -360,13 +401,14 @@ def main():
     # ---- headline: configs[1], one global stream, rank r takes frames [first, first + F)
     first, count = shard_frames(world * F, world, rank)
     assert count == F
-    (pcm,) = stream_slice(torch, device, "c2", first, F)
+    (pcm,) = stream_slices(torch, device, "c2", first, F)
     elapsed = timed_steps(lambda: enc.encode_long(pcm, None, F, mantissa16=True))
     kms = kernel_ms(lambda: enc.encode_long(pcm, None, F, mantissa16=True))
+    coded = coded_line_fraction(np, enc.encode_long(pcm, None, F, mantissa16=True), enc.h.bands(HOP, HOP))
     line = None
     if rank == 0:
         total_samples = float(F) * HOP * world * args.steps
-        ab = algorithmic_bytes(False, True, True)
+        ab = algorithmic_bytes(False, True, True, coded_line_frac=coded)
         traffic, traffic_src = measured_traffic("mono")
         rows = kernel_report(list(zip(KERNEL_NAMES, kms)), ab, F, traffic)
         smr_ms = float(kms[1])
@@ -392,90 +434,45 @@ def main():
                 "note": "dominant kernel by device time, priced against HBM as the contract asks; the HBM-bound kernel "
                         "of the path is mdct_long_kernel, see kernels[0]"}),
             "kernels": rows,
+            "coded_line_fraction": round(coded, 4),
             "whole_path": {"algorithmic_bytes_per_frame": ab["path"],
                            "achieved_GBs": round(ab["path"] * F * world * args.steps / elapsed / 1e9, 2)},
         }
 
+    Fx = min(args.extra_frames, F)                      # batch of the other configurations
     if not args.skip_extras:
         # ---- the float64-in / int32-out layout round 1 measured (continuity)
-        x64 = (torch.sign(pcm.double()) * 2.0 * torch.abs(pcm.double()) / 65535).contiguous()
-        e64 = timed_steps(lambda: enc.encode_long(x64, None, F))
-        k64 = kernel_ms(lambda: enc.encode_long(x64, None, F))
+        p64 = pcm[:(Fx + 1) * HOP].double()
+        x64 = (torch.sign(p64) * 2.0 * torch.abs(p64) / 65535).contiguous()
+        del p64
+        e64 = timed_steps(lambda: enc.encode_long(x64, None, Fx))
+        k64 = kernel_ms(lambda: enc.encode_long(x64, None, Fx))
         if rank == 0:
-            ab64 = algorithmic_bytes(False, False, False)
-            line["f64_layout"] = {"value": round(float(F) * HOP * world * args.steps / e64 / 1e6, 3), "unit": "Msamples/s",
-                                  "ms_per_step": round(e64 / args.steps * 1e3, 4),
+            ab64 = algorithmic_bytes(False, False, False, coded_line_frac=coded)
+            line["f64_layout"] = {"value": round(float(Fx) * HOP * world * args.steps / e64 / 1e6, 3), "unit": "Msamples/s",
+                                  "frames": Fx, "ms_per_step": round(e64 / args.steps * 1e3, 4),
                                   "layout": "float64 signed fractions in, int32 mantissa plane out (round-1 layout)",
-                                  "kernels": kernel_report(list(zip(KERNEL_NAMES, k64)), ab64, F, {})}
+                                  "kernels": kernel_report(list(zip(KERNEL_NAMES, k64)), ab64, Fx, {})}
         del x64
 
+    if not args.skip_extras:
+        # ---- SURVEY.md 8(d) metric as defined: page-locked host PCM -> codes in page-locked host memory.  At N > 1 every rank
+        # runs it at the same time on its own buffers (between barriers) and the slowest rank counts.
+        h2h = host_to_host_leg(np, torch, enc, device, args.h2h_frames, first, barrier,
+                               lambda v: max_over_ranks(v, coll_device), world)
+        if rank == 0:
+            line["host_to_host"] = h2h
+
     if world == 1 and not args.skip_extras:
-        # ---- SURVEY.md 8(d) metric as defined: page-locked host PCM -> codes in page-locked host memory
-        keep = []
-
-        def pin(shape, dt):
-            p = PinnedArray(shape, dt); keep.append(p); return p.array
-        # a stream of 4 F frames (SURVEY 8(d) C2 is 2^20): the pipeline's fill and drain (one chunk each) weigh less
-        Fh = args.h2h_frames or 4 * F
-        host_pcm = pin(((Fh + 1) * HOP,), np.int16)
-        for f0 in range(0, Fh, F):                          # generated on the device slice by slice (counter-based)
-            nfr = min(F, Fh - f0)
-            (part,) = stream_slice(torch, device, "c2", f0, nfr)
-            host_pcm[f0 * HOP:(f0 + nfr + 1) * HOP] = part.cpu().numpy()
-            del part
-        outs = dict(overall_scale=pin((Fh, 1), np.int32), scale_factor=pin((Fh, 1, NB), np.int32),
-                    bit_alloc=pin((Fh, 1, NB), np.int32), mantissa=pin((Fh, 1, HOP), np.uint16),
-                    reservoir_out=pin((Fh,), np.int32))
-        runs = {}
-        for chunk in (16384, 32768, 65536):
-            enc.h.encode_stream_pcm16(host_pcm, None, None, chunk, outs)        # warm-up: lane buffers, first touch
-            ts = []
-            for _ in range(5):
-                t0 = time.perf_counter()
-                enc.h.encode_stream_pcm16(host_pcm, None, None, chunk, outs)
-                ts.append(time.perf_counter() - t0)
-            runs[chunk] = float(np.median(ts))
-        best = min(runs, key=runs.get)
-        nchk = min(F, Fh)
-        dev_out = enc.encode_long(pcm[:(nchk + 1) * HOP].contiguous(), None, nchk, mantissa16=True)
-        same = bool(np.array_equal(dev_out["mantissa"].cpu().numpy().view(np.uint16), outs["mantissa"][:nchk]))
-        pcie = 2 * HOP + 2 * HOP + 2 * 4 * NB + 8
-        line["host_to_host"] = {
-            "value": round(Fh * HOP / runs[best] / 1e6, 3), "unit": "Msamples/s", "frames": Fh, "median_of": 5,
-            "chunk_frames": best, "by_chunk_frames": {str(k): round(Fh * HOP / v / 1e6, 1) for k, v in runs.items()},
-            "what": "int16 PCM in page-locked host memory -> H2D -> kernels -> D2H -> uint16 mantissas + int32 side info "
-                    "in page-locked host memory (mrc_encode_stream_pcm16, 3 HIP streams)",
-            "pcie_bytes_per_frame": pcie, "pcie_GBs_each_way": round(Fh * 2 * HOP / runs[best] / 1e9, 2),
-            "pcie_ceiling": "page-locked copies on this box (tools/pcie_rates.py): 55-57 GB/s one way alone, 25 / 47 GB/s "
-                            "each way with both directions busy at 16 / 64 MiB per copy",
-            "equals_resident_result": same}
-        del dev_out
-        # ... and with the back end on the device as well: the same PCM -> `.pac` chunk bytes in page-locked host memory
-        pac_buf = pin((Fh * HOP + 4096,), np.uint8)
-        pac_chunk = best
-        enc.h.encode_stream_pcm16_pac(host_pcm, None, None, True, pac_chunk, {"bytes": pac_buf})
-        ts = []
-        for _ in range(5):
-            t0 = time.perf_counter()
-            pac = enc.h.encode_stream_pcm16_pac(host_pcm, None, None, True, pac_chunk, {"bytes": pac_buf})
-            ts.append(time.perf_counter() - t0)
-        tp = float(np.median(ts))
-        line["host_to_host"]["pac"] = {
-            "value": round(Fh * HOP / tp / 1e6, 3), "unit": "Msamples/s", "chunk_frames": pac_chunk,
-            "bytes_per_frame": round(pac["bytes"].size / Fh, 1),
-            "what": "the same PCM -> .pac chunk bytes (Huffman pricing + bit packing on the device, mrc_encode_stream_pcm16_pac) "
-                    "in page-locked host memory"}
-        del pac
-        for p in keep:
-            p.free()
-
+        F = Fx                                             # (the configurations below run at the smaller batch)
+        pcm = pcm[:(F + 1) * HOP].contiguous()
         # ---- configs[2]: stereo, joint M/S path, resident
         Fs = F // 2
         sl, sr = stream_slice(torch, device, "c3", 0, Fs)
         es = timed_steps(lambda: enc.encode_long(sl, sr, Fs, mantissa16=True))
         ks = kernel_ms(lambda: enc.encode_long(sl, sr, Fs, mantissa16=True))
         out = enc.encode_long(sl, sr, Fs, mantissa16=True)
-        abj = algorithmic_bytes(True, True, True)
+        abj = algorithmic_bytes(True, True, True, coded_line_frac=coded_line_fraction(np, out, enc.h.bands(HOP, HOP)))
         tj, tj_src = measured_traffic("joint")
         rows_j = kernel_report(list(zip(KERNEL_NAMES, ks)), abj, Fs, tj)
         cfgs = {"stereo_ms": {
@@ -489,21 +486,50 @@ def main():
         cfgs["stereo_ms"]["device_pack"] = device_pack_rate(torch, enc, out, Fs, args.steps)
         del sl, sr, out
 
-        # ---- configs[3]: block switching (long / start / 8 short / stop), mono, resident
+        # ---- configs[3]: block switching (long / start / 8 short / stop), mono, resident.  The block shapes are the
+        # transient detector's on the content (pacfileThem.py:1025-1056, 1182-1214): its kernel runs inside the timed
+        # step, the O(hops) sequencing of its peaks is host logic done once (the content does not change between steps)
+        from mrcaudiocodec_amd import transient
         hops = F
         (xs,) = stream_slice(torch, device, "c4", 0, hops)
-        groups = {k: torch.tensor(v, dtype=torch.int64, device=device) for k, v in c4_shapes(hops).items()}
+        sos = transient.design_sos(48000)
+        peaks = torch.empty((hops, 1, HOP // 128 + 1), dtype=torch.float64, device=device)
+        t0 = time.perf_counter()
+        shp = transient.block_shape_array_dev(enc.h, xs.data_ptr(), 1, hops, 1, xs.numel(), sos)
+        t_seq = time.perf_counter() - t0
+        forced = c4_shapes(hops - 1)                                      # the cycle the content was built for
+        groups, n_written = {}, 0
+        for (a, b) in sorted({(int(r[1]), int(r[2])) for r in shp}):
+            sel = shp[(shp[:, 1] == a) & (shp[:, 2] == b), 0]
+            groups[(a, b)] = torch.from_numpy(np.ascontiguousarray(sel)).to(device)
+        n_written = int(shp[:, 2].sum()) // HOP
+        same_as_forced = all(k in forced and np.array_equal(np.asarray(forced[k]), groups[k].cpu().numpy()) for k in groups) \
+            and len(forced) == len(groups)
+        cur_stream = torch.cuda.current_stream(device).cuda_stream
+
+        def run_detector():
+            enc.h.dev_transient_peaks(hops, 1, sos, xs.data_ptr(), 1, xs.numel(), peaks.data_ptr(), cur_stream)
 
         def run_switched():
+            run_detector()
             for (a, b), o in groups.items():
                 enc.encode(a, b, xs, None, o.numel(), 0, o, mantissa16=True, offsets_checked=True)
         eb = timed_steps(run_switched)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(3):
+            run_detector()
+        ev1.record()
+        torch.cuda.synchronize(device)
+        det_ms = ev0.elapsed_time(ev1) / 3
         per_shape, rows_b = {}, []
         tb, tb_src = measured_traffic("switch")
         for (a, b), o in groups.items():
             km = kernel_ms(lambda: enc.encode(a, b, xs, None, o.numel(), 0, o, mantissa16=True, offsets_checked=True))
-            nb = len(enc.h.bands(a, b))
-            abk = algorithmic_bytes(False, True, True, a, b, nb)
+            bands_ab = enc.h.bands(a, b)
+            nb = len(bands_ab)
+            oo = enc.encode(a, b, xs, None, o.numel(), 0, o, mantissa16=True, offsets_checked=True)
+            abk = algorithmic_bytes(False, True, True, a, b, nb, coded_line_frac=coded_line_fraction(np, oo, bands_ab))
             label = dict(KERNEL_LABEL)
             if (a, b) != (HOP, HOP):
                 label["mdct"] = "mdct_kernel"
@@ -513,52 +539,38 @@ def main():
             rows_b += rr
             per_shape["%dx%d" % (a, b)] = {"blocks": int(o.numel()), "kernel_ms": [round(float(v), 4) for v in km]}
         cfgs["block_switching"] = {
-            "workload": "configs[3]: mono stream with a burst every 5th hop -> (1024,1024), (1024,128), 7x(128,128), (128,1024) "
-                        "blocks, one launch set per shape",
-            "value": round(float(hops) * HOP * args.steps / eb / 1e6, 3), "unit": "Msamples/s", "hops": hops,
+            "workload": "configs[3]: mono stream with a burst every 5th hop; block shapes from the transient detector on the "
+                        "content -> (1024,1024), (1024,128), 7x(128,128), (128,1024) blocks, one launch set per shape; the "
+                        "detector's kernel is part of the timed step",
+            "value": round(float(n_written) * HOP * args.steps / eb / 1e6, 3), "unit": "Msamples/s", "hops": n_written,
             "ms_per_step": round(eb / args.steps * 1e3, 4), "per_shape": per_shape,
+            "detector": {"kernel_ms": round(det_ms, 4), "peaks_to_shapes_host_s_once": round(t_seq, 3),
+                         "shapes_equal_forced_cycle": bool(same_as_forced),
+                         "what": "transient_peaks_kernel over %d hops (20th-order high-pass per hop from a zero state, one thread "
+                                 "per hop) + the look-ahead sequencing of its peaks on the host" % hops},
             "roofline": roofline_of(rows_b, {"traffic_source": tb_src,
                                              "traffic": None if "smr_kernel" not in tb else round(tb["smr_kernel"] * hops),
                                              "traffic_note": "smr_kernel, all four block shapes of a step together"}),
             "hbm_traffic_bytes_per_hop": {k: v for k, v in tb.items()} or None, "kernels": rows_b}
-        # ---- stream mode: MANY stereo streams advance one block per step, every stream's bit reservoir chained through the
-        # Huffman savings of its previous block on the device (codecThem.py:224,274) -- the mode that writes the files the
-        # reference writes; a step's batch is the number of streams, not the length of one
-        nS, nT = 8192, 12
-        gs = torch.Generator(device=device)
-        gs.manual_seed(7)
-        pl = torch.clamp(torch.round(torch.randn((nS, (nT + 1) * HOP), generator=gs, device=device, dtype=torch.float64) * 3000),
-                         -32767, 32767)
-        ssl = (torch.sign(pl) * 2.0 * torch.abs(pl) / 65535).contiguous()
-        ssl[:, :HOP] = 0
-        ssr = (0.7 * ssl + 0.3 * torch.roll(ssl, 17, dims=1)).contiguous()
-        ssr[:, :HOP] = 0
-        del pl
-        one = np.array([(i * HOP, HOP, HOP) for i in range(nT)], dtype=np.int64)
-        shapes_all = np.broadcast_to(one, (nS, nT, 3))
-        # warm-up with the WHOLE schedule: every step keeps its outputs (the packer reads them afterwards), 70 MB each --
-        # the caching allocator then holds the blocks the timed run takes again
-        warm = enc.encode_chained(ssl, ssr, shapes_all)
-        del warm
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        _, reservoir = enc.encode_chained(ssl, ssr, shapes_all)
-        torch.cuda.synchronize(device)
-        dt = time.perf_counter() - t0
-        cfgs["stream_mode"] = {
-            "workload": "%d stereo streams x %d chained joint long blocks, bit reservoirs carried from block to block on the "
-                        "device (encode kernels + Huffman pricing per step)" % (nS, nT),
-            "value": round(2.0 * nS * nT * HOP / dt / 1e6, 3), "unit": "Msamples/s", "ms_per_step": round(dt * 1e3 / nT, 4),
-            "mean_final_reservoir_bits": round(float(reservoir.double().mean().item()), 1)}
-        del ssl, ssr
+        del peaks
+        # ---- stream mode: MANY stereo streams, every stream's bit reservoir carried from block to block through the Huffman
+        # savings (codecThem.py:224,274) -- the mode that writes the files the reference writes.  ONE call
+        # (mrc_dev_encode_chained_pac): phase A batched over all blocks of all streams, the serial scan per stream on the
+        # device, `.pac` files (headers, Close()'s block) packed in HBM
+        cfgs["stream_mode"] = stream_mode_leg(np, torch, enc, device, 8192, 12, args.steps)
+        # ---- ONE long stereo stream -> one `.pac` file (the reference's only real use case, pacfileThem.py:1064-1231)
+        cfgs["single_stream"] = single_stream_leg(np, torch, enc, device, args.single_hops)
         line["configs"] = cfgs
         del xs, groups
 
     if world > 1 and not args.skip_extras:
-        # ---- configs[4]: the C3 stereo stream, frame-sharded, joint path, host pack reported separately
-        Fs = F // 2
+        # ---- configs[4]: the C3 stereo stream, frame-sharded, joint path, host pack reported separately.  10^7 / 8 frames per
+        # GPU (~54 GB of HBM: 10^7 frames at N = 8; the same per-GPU share at every N: weak scaling)
+        del pcm
+        torch.cuda.empty_cache()
+        Fs = args.c4_frames
         first_s, cnt = shard_frames(world * Fs, world, rank)
-        sl, sr = stream_slice(torch, device, "c3", first_s, Fs)
+        sl, sr = stream_slices(torch, device, "c3", first_s, Fs)
         es = timed_steps(lambda: enc.encode_long(sl, sr, Fs, mantissa16=True))
         out = enc.encode_long(sl, sr, Fs, mantissa16=True)
         pack = host_pack_rate(np, ppac, out, min(Fs, 16384), threads=max(1, min(16, (os.cpu_count() or 8) // world)))
@@ -566,6 +578,12 @@ def main():
         slowest = -max_over_ranks(-pack_rate, coll_device)            # min over ranks
         dpack = device_pack_rate(torch, enc, out, Fs, args.steps)
         dslow = -max_over_ranks(-dpack["huffman_priced_on_device_Msamples_s"], coll_device)
+        del sl, sr, out
+        torch.cuda.empty_cache()
+        # ---- stream mode across ranks: whole streams per rank ("with many streams, shard by stream"), no
+        # collective; the slowest rank's call counts
+        sm = stream_mode_leg(np, torch, enc, device, 8192, 12, args.steps, first_stream=rank * 8192)
+        sm_dt = max_over_ranks(sm["seconds_per_call"], coll_device)
         if rank == 0:
             line["configs4"] = {
                 "workload": "configs[4]: C3 stereo content as ONE stream of %d frames, frame-sharded x%d (contiguous ranges, "
@@ -579,6 +597,11 @@ def main():
                 "host_pack": dict(pack, note="Huffman table choice + bit packing of each rank's outputs on its share of the "
                                              "host cores (C++, csrc/mrc_pack.cpp), outside the timed GPU region; whole-job "
                                              "figure = world x the slowest rank's rate")}
+            sm["workload"] = "x%d ranks, each: %s" % (world, sm["workload"])
+            sm["value"] = round(2.0 * world * 8192 * 12 * HOP / sm_dt / 1e6, 3)
+            sm["seconds_per_call"] = round(sm_dt, 5)
+            sm["note"] += "; whole streams per rank, no collective, whole-job rate over the slowest rank's call"
+            line["stream_mode"] = sm
 
     if rank == 0:
         if cpu_line is not None:
@@ -588,6 +611,184 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def stream_mode_leg(np, torch, enc, device, nS, nT, steps, first_stream=0):
+    """nS stereo streams of nT long blocks each (+ Close()), resident int16 PCM -> `.pac` files in HBM, one chained call."""
+    gs = torch.Generator(device=device)
+    gs.manual_seed(7 + first_stream)
+    pl = torch.clamp(torch.round(torch.randn((nS, (nT + 1) * HOP), generator=gs, device=device, dtype=torch.float64) * 3000),
+                     -32767, 32767)
+    pl[:, :HOP] = 0
+    pr = torch.clamp(torch.round(0.7 * pl + 0.3 * torch.roll(pl, 17, dims=1)), -32767, 32767)
+    pr[:, :HOP] = 0
+    ssl, ssr = pl.to(torch.int16).contiguous(), pr.to(torch.int16).contiguous()
+    del pl, pr
+    one = np.array([(i * HOP, HOP, HOP) for i in range(nT)], dtype=np.int64)
+    shapes_all = [one] * nS
+    ns = [nT * HOP] * nS
+    r = enc.encode_chained_pac(ssl, ssr, shapes_all, num_samples=ns)                 # warm-up: buffers
+    out_buf = torch.empty((int(r["total"]) + 4096,), dtype=torch.uint8, device=device)
+    ts, ms = [], None
+    for _ in range(max(3, steps)):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        r = enc.encode_chained_pac(ssl, ssr, shapes_all, num_samples=ns, out=out_buf)
+        torch.cuda.synchronize(device)
+        ts.append(time.perf_counter() - t0)
+        if ms is None or ts[-1] == min(ts):
+            ms = enc.h.chain_ms()
+    dt = float(np.median(ts))
+    res = {"workload": "%d stereo streams x %d chained joint long blocks + Close(), int16 PCM resident in HBM -> complete .pac "
+                       "files in HBM; bit reservoirs carried from block to block on the device" % (nS, nT),
+           "value": round(2.0 * nS * nT * HOP / dt / 1e6, 3), "unit": "Msamples/s", "seconds_per_call": round(dt, 5),
+           "device_ms": {"phase_a_and_prep": round(float(ms[0]), 3), "serial_scan": round(float(ms[1]), 3),
+                         "pack": round(float(ms[2]), 3)},
+           "value_device_time_only": round(2.0 * nS * nT * HOP / (float(ms[3]) * 1e-3) / 1e6, 3),
+           "pac_bytes_per_stereo_frame": round(r["total"] / (nS * nT), 1),
+           "mean_final_reservoir_bits": round(float(np.mean(r["reservoir_out"])), 1),
+           "note": "the call's wall time includes building and uploading the schedule of %d blocks on the host" % (nS * nT)}
+    del ssl, ssr, out_buf
+    return res
+
+
+def single_stream_leg(np, torch, enc, device, hops):
+    """ONE stereo stream of `hops` hops with bursts: detector -> block shapes -> one chained call.  Resident and host to
+    host; the block-at-a-time loop (what this package did before the chained call, and what the reference does) timed on a
+    prefix as the 'before'."""
+    from mrcaudiocodec_amd import transient, pacfile as ppac, synth
+    both = torch.empty((2, (hops + 1) * HOP), dtype=torch.int16, device=device)
+    l, r = stream_slices(torch, device, "c5", 0, hops)
+    both[0], both[1] = l, r
+    del l, r
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    shp = transient.block_shape_array_dev(enc.h, both.data_ptr(), 1, hops, 2, both.shape[1])
+    t_det = time.perf_counter() - t0
+    last = len(shp)
+    while last > 0 and shp[last - 1, 2] != HOP:                           # Close() wants a long last block
+        last -= 1
+    shp = shp[:last]
+    samples = 2.0 * float(shp[:, 2].sum())
+    n_short = int((shp[:, 1] + shp[:, 2] != 2 * HOP).sum())
+    nsmp = [int(shp[:, 2].sum())]
+    rr = enc.encode_chained_pac(both[0:1], both[1:2], [shp], num_samples=nsmp)       # warm-up
+    out_buf = torch.empty((int(rr["total"]) + 4096,), dtype=torch.uint8, device=device)
+    best, ms = None, None
+    for _ in range(3):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        rr = enc.encode_chained_pac(both[0:1], both[1:2], [shp], num_samples=nsmp, out=out_buf)
+        torch.cuda.synchronize(device)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, ms = dt, enc.h.chain_ms()
+    host = both.cpu().numpy()
+    enc.h.encode_chained_pac(host[0:1], host[1:2], [shp], num_samples=nsmp)
+    t0 = time.perf_counter()
+    hh = enc.h.encode_chained_pac(host[0:1], host[1:2], [shp], num_samples=nsmp)
+    t_h2h = time.perf_counter() - t0
+    same = hh["bytes"].tobytes() == rr["bytes"].cpu().numpy().tobytes()
+    # before: the block-at-a-time loop on a prefix that ends with a long block
+    k = min(64, len(shp))
+    while k > 1 and shp[k - 1, 2] != HOP:
+        k -= 1
+    pre = [tuple(x) for x in shp[:k].tolist()]
+    xf = synth.pcm_to_float(host[:, :int(pre[-1][0] + pre[-1][1] + pre[-1][2]) + HOP])
+    ppac.encode_stereo_stream_per_block(enc.h, xf, pre[:1])
+    t0 = time.perf_counter()
+    ref = ppac.encode_stereo_stream_per_block(enc.h, xf, pre)
+    t_loop = time.perf_counter() - t0
+    pre_new = enc.h.encode_chained_pac(host[0:1], host[1:2], [pre], num_samples=[sum(b for (_, _, b) in pre)])
+    loop_rate = 2.0 * sum(b for (_, _, b) in pre) / t_loop / 1e6
+    res = {"workload": "ONE stereo 48 kHz stream of %d hops (noise floor + tone, a burst every 37th hop), block shapes from the "
+                       "transient detector: %d blocks, %d of them short / transition; WAV samples -> one complete .pac file"
+                       % (hops, len(shp), n_short),
+           "value": round(samples / best / 1e6, 3), "unit": "Msamples/s", "what": "int16 PCM resident in HBM -> .pac bytes in HBM",
+           "seconds_per_call": round(best, 5),
+           "device_ms": {"phase_a_and_prep": round(float(ms[0]), 3), "serial_scan": round(float(ms[1]), 3),
+                         "pack": round(float(ms[2]), 3)},
+           "phase_b_us_per_block": round(1e3 * float(ms[1]) / (len(shp) + 2), 3),
+           "host_to_host": {"value": round(samples / t_h2h / 1e6, 3), "unit": "Msamples/s", "bytes_equal_resident": bool(same),
+                            "what": "int16 PCM in host memory -> .pac file in host memory (mrc_encode_chained_stream_pcm16_pac)"},
+           "detector_seconds": round(t_det, 4),
+           "before_per_block_loop": {"blocks": len(pre), "ms_per_block": round(1e3 * t_loop / len(pre), 4),
+                                     "Msamples_s": round(loop_rate, 3),
+                                     "bytes_equal_chained_call": bool(pre_new["bytes"].tobytes() == ref),
+                                     "what": "pacfile.encode_stereo_stream_per_block: one mrc_encode_joint + host pack per block, "
+                                             "the reservoir carried on the host (the round-2 path of cli.encode_wav)"},
+           "speedup_vs_per_block_loop": round(samples / best / 1e6 / loop_rate, 1),
+           "pac_bytes": int(rr["total"])}
+    del both, out_buf
+    return res
+
+
+def host_to_host_leg(np, torch, enc, device, Fh, first_frame, barrier, max_ranks, world):
+    """int16 PCM in page-locked host memory -> H2D -> kernels -> D2H -> codes in page-locked host memory
+    (mrc_encode_stream_pcm16, 3 HIP streams), median of 5 runs per chunk size; then the same PCM to `.pac` chunk bytes
+    (mrc_encode_stream_pcm16_pac).  Every rank measures between barriers; the times reported are the max over ranks."""
+    from mrcaudiocodec_amd import PinnedArray
+    keep = []
+
+    def pin(shape, dt):
+        p = PinnedArray(shape, dt); keep.append(p); return p.array
+    host_pcm = pin(((Fh + 1) * HOP,), np.int16)
+    piece = 1 << 17
+    for f0 in range(0, Fh, piece):                          # generated on the device piece by piece (counter-based)
+        nfr = min(piece, Fh - f0)
+        (part,) = stream_slice(torch, device, "c2", first_frame + f0, nfr)
+        host_pcm[f0 * HOP:(f0 + nfr + 1) * HOP] = part.cpu().numpy()
+        del part
+    outs = dict(overall_scale=pin((Fh, 1), np.int32), scale_factor=pin((Fh, 1, NB), np.int32),
+                bit_alloc=pin((Fh, 1, NB), np.int32), mantissa=pin((Fh, 1, HOP), np.uint16),
+                reservoir_out=pin((Fh,), np.int32))
+    runs = {}
+    for chunk in (16384, 32768, 65536):
+        enc.h.encode_stream_pcm16(host_pcm, None, None, chunk, outs)        # warm-up: lane buffers, first touch
+        ts = []
+        for _ in range(5):
+            barrier()
+            t0 = time.perf_counter()
+            enc.h.encode_stream_pcm16(host_pcm, None, None, chunk, outs)
+            ts.append(max_ranks(time.perf_counter() - t0))
+        runs[chunk] = float(np.median(ts))
+    best = min(runs, key=runs.get)
+    nchk = min(1 << 15, Fh)
+    dev_pcm = torch.from_numpy(host_pcm[:(nchk + 1) * HOP].copy()).to(device)
+    dev_out = enc.encode_long(dev_pcm, None, nchk, mantissa16=True)
+    same = bool(np.array_equal(dev_out["mantissa"].cpu().numpy().view(np.uint16), outs["mantissa"][:nchk]))
+    pcie = 2 * HOP + 2 * HOP + 2 * 4 * NB + 8
+    res = {
+        "value": round(world * Fh * HOP / runs[best] / 1e6, 3), "unit": "Msamples/s", "frames_per_gpu": Fh, "median_of": 5,
+        "chunk_frames": best, "by_chunk_frames": {str(k): round(world * Fh * HOP / v / 1e6, 1) for k, v in runs.items()},
+        "what": "int16 PCM in page-locked host memory -> H2D -> kernels -> D2H -> uint16 mantissas + int32 side info "
+                "in page-locked host memory (mrc_encode_stream_pcm16, 3 HIP streams); every rank its own buffers, all ranks "
+                "at once, whole-job rate over the slowest rank's time",
+        "pcie_bytes_per_frame": pcie, "pcie_GBs_each_way_per_gpu": round(Fh * 2 * HOP / runs[best] / 1e9, 2),
+        "pcie_ceiling": "page-locked copies on a one-GPU box (tools/pcie_rates.py): 55-57 GB/s one way alone, 25 / 47 GB/s "
+                        "each way with both directions busy at 16 / 64 MiB per copy",
+        "equals_resident_result": same}
+    del dev_out, dev_pcm
+    # ... and with the back end on the device as well: the same PCM -> `.pac` chunk bytes in page-locked host memory
+    pac_buf = pin((Fh * HOP + 4096,), np.uint8)
+    enc.h.encode_stream_pcm16_pac(host_pcm, None, None, True, best, {"bytes": pac_buf})
+    ts = []
+    for _ in range(5):
+        barrier()
+        t0 = time.perf_counter()
+        pac = enc.h.encode_stream_pcm16_pac(host_pcm, None, None, True, best, {"bytes": pac_buf})
+        ts.append(max_ranks(time.perf_counter() - t0))
+    tp = float(np.median(ts))
+    res["pac"] = {
+        "value": round(world * Fh * HOP / tp / 1e6, 3), "unit": "Msamples/s", "chunk_frames": best,
+        "bytes_per_frame": round(pac["bytes"].size / Fh, 1),
+        "what": "the same PCM -> .pac chunk bytes of INDEPENDENT frames (no reservoir chaining: every frame starts from "
+                "reservoir_in; Huffman pricing + bit packing on the device, mrc_encode_stream_pcm16_pac) in page-locked host "
+                "memory.  The reference-equivalent WAV -> .pac rates are configs.stream_mode / configs.single_stream"}
+    del pac
+    for p in keep:
+        p.free()
+    return res
 
 
 def device_pack_rate(torch, enc, out, n, steps):

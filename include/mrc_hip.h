@@ -195,6 +195,11 @@ int mrc_pcm_to_float(mrc_handle* h, int64_t n, const int16_t* pcm, double* out);
  * mrcaudiocodec_amd/transient.py. */
 int mrc_transient_peaks(mrc_handle* h, int64_t n_hops, int n_channels, int n_sections, const double* sos,
                         const double* streams, double* peaks);
+/* The same on streams that are already in DEVICE memory, as float64 signed fractions or as the file's int16 PCM codes
+ * (converted on load, pcmfile.py:91-100): channel c starts at streams + c * channel_stride samples; peaks (device)
+ * [n_hops][n_channels][nMDCTLines/nSamplesShort + 1]; sos is a HOST pointer.  Enqueued on `stream`. */
+int mrc_dev_transient_peaks(mrc_handle* h, int64_t n_hops, int n_channels, int n_sections, const double* sos,
+                            const void* streams, int sample_format, int64_t channel_stride, double* peaks, void* stream);
 /* ms_stereo.py:53-67 elementwise over n lines: out_mid = max(mid, min(side, MLD side)), out_side likewise, MLD from z
  * (Bark).  Kept for the drop-in module's symbol; the encoder's own use of it is dead (psychoac.py:205-210). */
 int mrc_stereo_masking_factor(mrc_handle* h, int64_t n, const double* mid_thresh, const double* side_thresh,

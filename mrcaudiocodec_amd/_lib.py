@@ -75,6 +75,8 @@ def _load():
         "mrc_scale_factor": (C.c_int, [H, C.c_int64, C.c_int, _f64p, _i32p, _i32p]),
         "mrc_mantissa": (C.c_int, [H, C.c_int64, C.c_int, _f64p, _i32p, _i32p, _i32p]),
         "mrc_transient_peaks": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, _f64p, _f64p, _f64p]),
+        "mrc_dev_transient_peaks": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, _f64p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p,
+                                              C.c_void_p]),
         "mrc_stereo_masking_factor": (C.c_int, [H, C.c_int64, _f64p, _f64p, _f64p, _f64p, _f64p]),
         "mrc_ms_switch": (C.c_int, [H, C.c_int64, C.c_int, _i32p, _f64p, _f64p, _i32p]),
         "mrc_dev_mdct": (C.c_int, [H, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
@@ -615,6 +617,12 @@ class Handle:
         self._check(lib.mrc_transient_peaks(self._h, n_hops, x.shape[0], sos.shape[0], _p(sos, _f64p), _p(x, _f64p),
                                             _p(out, _f64p)))
         return out
+
+    def dev_transient_peaks(self, n_hops, n_channels, sos, streams_ptr, sample_format, channel_stride, peaks_ptr, stream=None):
+        """mrc_dev_transient_peaks: streams / peaks are device addresses, sos a host array [nSections][6]."""
+        sos = _f64(sos)
+        self._check(lib.mrc_dev_transient_peaks(self._h, int(n_hops), int(n_channels), sos.shape[0], _p(sos, _f64p), streams_ptr,
+                                                int(sample_format), int(channel_stride), peaks_ptr, stream))
 
     def stereo_masking_factor(self, mid_thresh, side_thresh, z):
         m, s_, zz = _f64(mid_thresh), _f64(side_thresh), _f64(z)

@@ -116,6 +116,40 @@ class StreamEncoder:
                                 _ptr(table), _ptr(saved), _ptr(nxt), torch.cuda.current_stream(self.device).cuda_stream)
         return table, saved, nxt
 
+    def encode_chained_pac(self, left, right, shapes, use_huffman=True, with_flush=True, num_samples=None, reservoir_in=None,
+                           out=None):
+        """The reference's whole encode loop for stereo streams that are RESIDENT in HBM (mrc_dev_encode_chained_pac): left /
+        right [nStreams][stride] device tensors (int16 PCM codes or float64), shapes[s] = the (offset, a, b) sequence of
+        stream s (lists or int arrays [n][3]).  -> dict: bytes (device uint8 tensor, the used prefix), stream_offset /
+        item_offset / reservoir_out (host arrays), total; `out`: a device uint8 tensor to write into (else allocated at the
+        worst-case size)."""
+        from . import _lib
+        if left.dim() == 1:
+            left, right = left[None], right[None]
+        for t in (left, right):
+            if not t.is_cuda or not t.is_contiguous():
+                raise ValueError("device-contiguous tensors expected")
+        if left.dtype not in (torch.float64, torch.int16) or right.dtype != left.dtype or right.shape != left.shape:
+            raise ValueError("left / right: float64 or int16 [nStreams][stride], alike")
+        if len(shapes) != left.shape[0]:
+            raise ValueError("one shape list per stream expected")
+        if out is None:
+            start, _, a, b = self.h._chain_schedule(shapes)
+            C = _lib.C
+            bound = int(_lib.lib.mrc_chain_out_bound(self.h._h, len(shapes), start.ctypes.data_as(_lib._i64p),
+                                                     a.ctypes.data_as(_lib._i32p), b.ctypes.data_as(_lib._i32p),
+                                                     1 if with_flush else 0, 0 if num_samples is None else 1))
+            if bound < 0:
+                raise _lib.MrcError("mrc_chain_out_bound failed (%d)" % bound)
+            out = torch.empty((max(bound, 1),), dtype=torch.uint8, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        r = self.h.encode_chained_pac(None, None, shapes, use_huffman=use_huffman, with_flush=with_flush,
+                                      num_samples=num_samples, reservoir_in=reservoir_in,
+                                      device=(left.data_ptr(), right.data_ptr(), 1 if left.dtype == torch.int16 else 0,
+                                              left.shape[1], out.data_ptr(), out.numel()), stream=stream)
+        r["bytes"] = out[:r["total"]]
+        return r
+
     def encode_chained(self, left, right, shapes, use_huffman=True):
         """Stream mode for MANY stereo streams at once: left/right [nStreams][samples] on the device (each row
         starts with its zero prior hop), shapes[s] = the (offset, a, b) sequence of stream s (lists, or ONE int64 array [nStreams][nBlocks][3]).  Step t encodes the

@@ -1111,9 +1111,29 @@ int mrc_transient_peaks(mrc_handle* h, int64_t n_hops, int n_channels, int n_sec
     const size_t outBytes = (size_t)n_hops * n_channels * (hop / nShort + 1) * sizeof(double);
     MRC_HIP(h, h->outG.reserve(outBytes));
     MRC_HIP(h, launch_transient_peaks(n_hops, n_channels, hop, nShort, n_sections, h->inAux3.as<double>(),
-                                      h->inL.as<double>(), chStride, h->outG.as<double>(), h->stream));
+                                      h->inL.p, kSampleF64, chStride, h->outG.as<double>(), h->stream));
     MRC_TRY(s.down(peaks, h->outG, outBytes));
     MRC_HIP(h, hipStreamSynchronize(h->stream));
+    return MRC_OK;
+}
+
+int mrc_dev_transient_peaks(mrc_handle* h, int64_t n_hops, int n_channels, int n_sections, const double* sos,
+                            const void* streams, int sample_format, int64_t channel_stride, double* peaks, void* stream) {
+    if (!h || !sos || !streams || !peaks || n_hops < 0 || n_channels < 1 || n_sections < 1 || n_sections > 16 ||
+        (sample_format != MRC_SAMPLES_F64 && sample_format != MRC_SAMPLES_PCM16))
+        return fail(h, MRC_ERR_INVALID, "mrc_dev_transient_peaks: bad argument (1 <= n_sections <= 16)");
+    if (n_hops == 0) return MRC_OK;
+    const int hop = h->cfg.n_mdct_lines, nShort = h->cfg.n_short;
+    if (hop % nShort != 0) return fail(h, MRC_ERR_INVALID, "mrc_dev_transient_peaks: n_mdct_lines must be a multiple of n_short");
+    if (channel_stride < (n_hops + 1) * (int64_t)hop) return fail(h, MRC_ERR_INVALID, "mrc_dev_transient_peaks: channel_stride too small");
+    MRC_HIP(h, hipSetDevice(h->device));
+    hipStream_t st = pick_stream(h, stream);
+    // (the filter coefficients are 6 doubles per section: staged in the handle; the copy is ordered on `st`)
+    MRC_HIP(h, h->inAux3.reserve((size_t)n_sections * 6 * sizeof(double)));
+    MRC_HIP(h, hipMemcpyAsync(h->inAux3.p, sos, (size_t)n_sections * 6 * sizeof(double), hipMemcpyHostToDevice, st));
+    MRC_HIP(h, hipStreamSynchronize(st));                    // `sos` may be a temporary of the caller
+    MRC_HIP(h, launch_transient_peaks(n_hops, n_channels, hop, nShort, n_sections, h->inAux3.as<double>(), streams,
+                                      sample_format, channel_stride, peaks, st));
     return MRC_OK;
 }
 

@@ -132,14 +132,15 @@ __global__ void unscale_kernel(int halfN, int64_t total, const double* __restric
 // same operation order) and the peak |y| of each short sub-block plus the peak of the whole hop are kept.
 // One thread per (hop, channel): the recurrence is serial in time, hops are independent.
 constexpr int kMaxSections = 16;
+template <class SampleT>
 __global__ void transient_peaks_kernel(int64_t nHops, int nCh, int hop, int nShort, int nSec,
-                                       const double* __restrict__ sos, const double* __restrict__ streams,
+                                       const double* __restrict__ sos, const SampleT* __restrict__ streams,
                                        int64_t chStride, double* __restrict__ peaks) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nHops * nCh) return;
     const int64_t h = t / nCh;
     const int ch = (int)(t % nCh);
-    const double* x = streams + ch * chStride + (h + 1) * hop;          // the stream starts with the prior hop
+    const SampleT* x = streams + ch * chStride + (h + 1) * hop;         // the stream starts with the prior hop
     const int nSub = hop / nShort;
     double* out = peaks + t * (nSub + 1);
     double z0[kMaxSections], z1[kMaxSections];
@@ -149,7 +150,7 @@ __global__ void transient_peaks_kernel(int64_t nHops, int nCh, int hop, int nSho
     for (int sb = 0; sb < nSub; ++sb) {
         double pk = 0.0;
         for (int n = 0; n < nShort; ++n) {
-            double cur = x[sb * nShort + n];
+            double cur = sample_of(x, sb * nShort + n);
 #pragma unroll
             for (int s = 0; s < kMaxSections; ++s) {
                 if (s < nSec) {
@@ -312,11 +313,15 @@ hipError_t launch_mantissa(int64_t n, int nScaleBits, const double* x, const int
 }
 
 hipError_t launch_transient_peaks(int64_t nHops, int nCh, int hop, int nShort, int nSec, const double* sos,
-                                  const double* streams, int64_t chStride, double* peaks, hipStream_t st) {
+                                  const void* streams, int fmt, int64_t chStride, double* peaks, hipStream_t st) {
     const int64_t n = nHops * nCh;
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(transient_peaks_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, nHops, nCh, hop, nShort,
-                       nSec, sos, streams, chStride, peaks);
+    if (fmt == kSampleI16)
+        hipLaunchKernelGGL(transient_peaks_kernel<short>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, nHops, nCh, hop,
+                           nShort, nSec, sos, (const short*)streams, chStride, peaks);
+    else
+        hipLaunchKernelGGL(transient_peaks_kernel<double>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, nHops, nCh, hop,
+                           nShort, nSec, sos, (const double*)streams, chStride, peaks);
     return hipGetLastError();
 }
 

@@ -48,17 +48,40 @@ def block_shapes(handle, stream, sos=None, T=THRESHOLDS):
 
 
 def shapes_from_flags(flags, hop, n_short):
-    """pacfileThem.py:1182-1214 given the per-hop transient positions (bool [nHops][nSub])."""
+    """pacfileThem.py:1182-1214 given the per-hop transient positions (bool [nHops][nSub]) -> list of (offset, a, b)."""
+    return [tuple(r) for r in shape_array_from_flags(flags, hop, n_short).tolist()]
+
+
+def shape_array_from_flags(flags, hop, n_short):
+    """The same as ONE int64 array [nBlocks][3] = (offset, a, b) per block, without a Python loop over the hops: hop i
+    (the last one excepted: it is analysed but never written) becomes nSub short blocks if sum(blksw_i) > 1 or
+    any(blksw_{i+1} == 1), else one long block; `a` of a block is the `b` of the block before it, the offset the sum of
+    the a's before it (pacfileThem.py:1192-1210)."""
+    flags = np.asarray(flags, dtype=bool)
     nSub = hop // n_short
+    if flags.shape[0] < 2:
+        return np.zeros((0, 3), np.int64)
     pos = np.arange(1, nSub + 1)
-    sum_pos = (flags * pos).sum(axis=1)           # np.sum(blkswMem)
-    first = flags[:, 0]                           # any(blksw == 1)
-    shapes = []
-    off, a = 0, hop
-    for i in range(flags.shape[0] - 1):
-        if sum_pos[i] > 1 or first[i + 1]:
-            for _ in range(nSub):
-                shapes.append((off, a, n_short)); off += a; a = n_short
-        else:
-            shapes.append((off, a, hop)); off += a; a = hop
-    return shapes
+    sum_pos = (flags * pos).sum(axis=1)
+    short = (sum_pos[:-1] > 1) | flags[1:, 0]                          # per written hop
+    b = np.where(np.repeat(short, np.where(short, nSub, 1)), n_short, hop).astype(np.int64)
+    a = np.empty_like(b)
+    a[0] = hop
+    a[1:] = b[:-1]
+    off = np.zeros_like(b)
+    off[1:] = np.cumsum(a)[:-1]
+    return np.stack([off, a, b], axis=1)
+
+
+def block_shape_array_dev(handle, streams_ptr, sample_format, n_hops, n_channels, channel_stride, sos=None, T=THRESHOLDS,
+                          stream=None):
+    """block_shapes for a stream that is already in DEVICE memory (int16 PCM codes or float64): the filtering runs there
+    (mrc_dev_transient_peaks), only the peaks (9 doubles per hop and channel) come back.  -> int64 [nBlocks][3]."""
+    import torch
+    hop, n_short = handle.cfg.n_mdct_lines, handle.cfg.n_short
+    sos = design_sos(handle.cfg.sample_rate) if sos is None else sos
+    dev = torch.device("cuda", handle.cfg.device_id)
+    peaks = torch.empty((n_hops, n_channels, hop // n_short + 1), dtype=torch.float64, device=dev)
+    handle.dev_transient_peaks(n_hops, n_channels, sos, streams_ptr, sample_format, channel_stride, peaks.data_ptr(),
+                               torch.cuda.current_stream(dev).cuda_stream if stream is None else stream)
+    return shape_array_from_flags(transient_positions(peaks.cpu().numpy(), T), hop, n_short)

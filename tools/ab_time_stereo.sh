@@ -6,7 +6,7 @@ for round in 1 2; do
     for v in default "$@"; do
         lib=$repo/mrcaudiocodec_amd/libmrc_hip.so
         [ "$v" != default ] && lib=$repo/mrcaudiocodec_amd/libmrc_hip_$v.so
-        MRC_HIP_LIBRARY=$lib timeout -k 10 120 python bench.py --cpu-frames 0 --only stereo 2>/dev/null | tail -1 | sed "s/^/$v $round /" >> gpurun_out/${pre}_stereo.txt
+        MRC_HIP_LIBRARY=$lib timeout -k 10 120 python bench.py --frames 131072 --cpu-frames 0 --only stereo 2>/dev/null | tail -1 | sed "s/^/$v $round /" >> gpurun_out/${pre}_stereo.txt
     done
 done
 cat gpurun_out/${pre}_stereo.txt
