@@ -114,6 +114,30 @@ __device__ __forceinline__ void load_pair(const T* __restrict__ L, const T* __re
     *e = v.x; *o = v.y;
 }
 
+// A sample pair as it sits in memory -- 4 bytes of int16 PCM codes or 16 bytes of float64 -- loaded now, converted when
+// the unit that needs it starts: the REUSE variants request the NEXT unit's new hop while the current unit is transformed
+// (a wave's unit is one dependent chain load -> FFT -> store, and only two waves share a SIMD: without this the HBM
+// latency of every hop is exposed).
+template <class T> struct RawPair;
+template <> struct RawPair<short> {
+    int v;
+    __device__ __forceinline__ void load(const short* __restrict__ p, int64_t i) { v = *reinterpret_cast<const int*>(p + i); }
+    __device__ __forceinline__ double2 get() const { return make_double2(dev::pcm16_to_frac((short)(v & 0xffff)), dev::pcm16_to_frac(v >> 16)); }
+};
+template <> struct RawPair<double> {
+    double2 v;
+    __device__ __forceinline__ void load(const double* __restrict__ p, int64_t i) { v = *reinterpret_cast<const double2*>(p + i); }
+    __device__ __forceinline__ double2 get() const { return v; }
+};
+// the pair of signal `sig` (0 L, 1 R, 2 M = (L+R)/2, 3 S = (L-R)/2: codecThem.py:363-364) from the raw pairs of L and R
+template <class T>
+__device__ __forceinline__ double2 signal_from_raw(const RawPair<T>& l, const RawPair<T>& r, int sig) {
+    if (sig == 0) return l.get();
+    if (sig == 1) return r.get();
+    const double2 a = l.get(), b = r.get();
+    return sig == 2 ? make_double2((a.x + b.x) / 2.0, (a.y + b.y) / 2.0) : make_double2((a.x - b.x) / 2.0, (a.y - b.y) / 2.0);
+}
+
 // pre[lane + 64 r] = pre[lane] * W32^r and post[lane + 64 q] = post[lane] * W32^q (both tables are unit-circle
 // points whose angle is affine in the index with step 2 pi/2048 resp. 4 * 2 pi/4096 per index)
 template <int R> __device__ __forceinline__ double2 twiddle_lane(double2 v, double2 laneConst) {
@@ -128,7 +152,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void mdct_long_kernel(
     const int64_t* __restrict__ offsets, double* __restrict__ lines, int* __restrict__ oscale) {
     __shared__ __attribute__((aligned(16))) double smem[kWavesPerBlock * kWaveLds + 2 * kQ];
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // a scalar: unit, signal, offset and every branch on them are wave-uniform
     double* ws = smem + wave * kWaveLds;                               // this wave's 16 KiB
     double2* w512 = reinterpret_cast<double2*>(smem + kWavesPerBlock * kWaveLds);   // [512] e^{-2 pi i t/512}
     for (int i = threadIdx.x; i < kQ; i += kWave * kWavesPerBlock) w512[i] = S.wQ[i];
@@ -153,11 +177,36 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void mdct_long_kernel(
     else { firstUnit = (int64_t)blockIdx.x * kWavesPerBlock * kRun + wave; step = kWavesPerBlock; }
 
     double rawE[8], rawO[8];                    // REUSE: raw second half of the previous block (= first half of this one)
-    if (REUSE && firstUnit < nUnits) {
-        const int64_t off = (firstUnit / NSIG) * stride;
-        const int sig0 = (int)(firstUnit % NSIG);
+    // REUSE: the new hop of the coming unit, requested one unit ahead -- for int16 PCM (8 registers per channel); float64
+    // samples would take 32 per channel, more than the wave has left: they are loaded when their unit starts
+#ifndef MRC_MDCT_AHEAD                           // 0: never, 1: joint blocks only, 2: mono and joint.  Measured (tools/mdct_bench.py, ms per
+                                                 // 131 072 mono / 65 536 joint frames): 0.358 / 1.136, 0.352 / 0.950, 0.361 / 0.945
+#define MRC_MDCT_AHEAD 1
+#endif
+    constexpr bool kAhead = sizeof(T) == 2 && (MRC_MDCT_AHEAD == 2 || (MRC_MDCT_AHEAD == 1 && NSIG != 1));
+    RawPair<T> nxtL[kAhead ? 8 : 1], nxtR[kAhead ? 8 : 1];
+    int64_t prevOff = 0;
+    auto unit_off = [&](int64_t unit) -> int64_t {
+        const int64_t f = NSIG == 1 ? unit : unit / NSIG;
+        return offsets ? offsets[f] : f * stride;
+    };
+    auto request_new_hop = [&](int64_t off, int sig) {          // samples [off + 1024, off + 2048): aligned pairs only
+        if (!kAhead) return;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) load_pair<NSIG, T>(chL, chR, off + 2 * (lane + 64 * c), sig0, &rawE[c], &rawO[c]);
+        for (int c = 0; c < (kAhead ? 8 : 0); ++c) {
+            const int64_t i = off + 2 * (lane + 64 * (c + 8));
+            if (NSIG == 1 || sig != 1) nxtL[c].load(chL, i);
+            if (NSIG != 1 && sig != 0) nxtR[c].load(chR, i);
+        }
+    };
+    if (REUSE && firstUnit < nUnits) {
+        const int64_t off = unit_off(firstUnit);
+        const int sig0 = (int)(firstUnit % NSIG);
+        const bool al = !(off & 1);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) load_pair<NSIG, T>(chL, chR, off + 2 * (lane + 64 * c), sig0, &rawE[c], &rawO[c], al);
+        if (al) request_new_hop(off, sig0);
+        prevOff = off - kM;                                      // (so that the first unit counts as a continuation)
     }
 
     for (int it = 0; it < kRun; ++it) {
@@ -165,25 +214,61 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock, 2) void mdct_long_kernel(
         if (unit >= nUnits) break;                                     // wave-uniform
         const int64_t f = NSIG == 1 ? unit : unit / NSIG;
         const int sig = NSIG == 1 ? 0 : (int)(unit % NSIG);
-        const int64_t off = (!REUSE && offsets) ? offsets[f] : f * stride;
-        const bool aligned = REUSE || !(off & 1);
+        const int64_t off = (REUSE || offsets) ? unit_off(unit) : f * stride;
+        const bool aligned = !(off & 1);
+        // REUSE: this block continues the previous one of the wave (its first half is in rawE / rawO and its second half
+        // was requested a unit ago) -- always in a strided stream, and for explicit offsets whenever they are a hop apart
+        // (a block-switched stream is mostly runs of long blocks); else the whole block is loaded here
+        const bool cont = REUSE && aligned && off == prevOff + kM;     // wave-uniform
 
         // ---- A. coalesced load (16 B per lane), window, de-interleave into yE / yO
         double* yE = ws;
         double* yO = ws + kM;
+        if (cont) {
+            double2 cur[8];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-            const int i = lane + 64 * c;
-            double e, o;
-            if (REUSE && c < 8) {
-                e = rawE[c]; o = rawO[c];
-            } else {
-                load_pair<NSIG, T>(chL, chR, off + 2 * i, sig, &e, &o, aligned);
-                if (REUSE) { rawE[c & 7] = e; rawO[c & 7] = o; }
+            for (int c = 0; c < 8; ++c) {
+                if (kAhead) cur[c] = NSIG == 1 ? nxtL[kAhead ? c : 0].get() : signal_from_raw<T>(nxtL[kAhead ? c : 0], nxtR[kAhead ? c : 0], sig);
+                else load_pair<NSIG, T>(chL, chR, off + 2 * (lane + 64 * (c + 8)), sig, &cur[c].x, &cur[c].y, true);
             }
-            yE[i] = e * wE[c];
-            yO[i] = o * wO[c];
+            // the next unit's new hop (if it continues this one; if not, it is loaded when its turn comes)
+            const int64_t nu = unit + step;
+            if (it + 1 < kRun && nu < nUnits) {
+                const int64_t offN = unit_off(nu);
+                if (offN == off + kM) request_new_hop(offN, sig);
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int i = lane + 64 * c;
+                yE[i] = rawE[c] * wE[c];
+                yO[i] = rawO[c] * wO[c];
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int i = lane + 64 * (c + 8);
+                rawE[c] = cur[c].x; rawO[c] = cur[c].y;
+                yE[i] = cur[c].x * wE[c + 8];
+                yO[i] = cur[c].y * wO[c + 8];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+                const int i = lane + 64 * c;
+                double e, o;
+                load_pair<NSIG, T>(chL, chR, off + 2 * i, sig, &e, &o, aligned);
+                if (REUSE && c >= 8) { rawE[c & 7] = e; rawO[c & 7] = o; }
+                yE[i] = e * wE[c];
+                yO[i] = o * wO[c];
+            }
+            if (REUSE) {
+                const int64_t nu = unit + step;
+                if (it + 1 < kRun && nu < nUnits) {
+                    const int64_t offN = unit_off(nu);
+                    if (offN == off + kM && !(offN & 1)) request_new_hop(offN, sig);
+                }
+            }
         }
+        prevOff = off;
         wave_sync();
         // ---- B. fold N -> N/2 -> 512 complex points (n = lane + 64 r), pre-twiddle
         double2 u[8];
@@ -270,13 +355,17 @@ static void launch_long_t(const DevShape& S, int64_t nFrames, const T* chL, cons
     const int64_t perBlock = (int64_t)kWavesPerBlock * kRun;
     const unsigned grid = (unsigned)((nUnits + perBlock - 1) / perBlock);
     const dim3 block(kWave * kWavesPerBlock);
-    if (nsig == 4 && !offsets && stride == kM)       // hop-overlapped stereo stream: one wave per signal, hops kept
+    // hop-overlapped stream (stride one hop), or explicit offsets (a block-switched stream: mostly runs of blocks a hop
+    // apart, detected per block): a wave walks consecutive frames of one signal and keeps / prefetches hops.  Explicit
+    // blocks at another stride: the four waves take adjacent units.
+    const bool reuse = offsets ? true : stride == kM;
+    if (nsig == 4 && reuse)
         hipLaunchKernelGGL((mdct_long_kernel<4, true, T>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, offsets,
                            lines, oscale);
     else if (nsig == 4)
         hipLaunchKernelGGL((mdct_long_kernel<4, false, T>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, offsets,
                            lines, oscale);
-    else if (!offsets && stride == kM)               // hop-overlapped stream: consecutive frames share a hop
+    else if (reuse)
         hipLaunchKernelGGL((mdct_long_kernel<1, true, T>), dim3(grid), block, 0, st, S, nUnits, chL, chR, stride, offsets,
                            lines, oscale);
     else
