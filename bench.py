@@ -624,9 +624,10 @@ def stream_mode_leg(np, torch, enc, device, nS, nT, steps, first_stream=0):
     pr[:, :HOP] = 0
     ssl, ssr = pl.to(torch.int16).contiguous(), pr.to(torch.int16).contiguous()
     del pl, pr
+    from mrcaudiocodec_amd import ChainSchedule
     one = np.array([(i * HOP, HOP, HOP) for i in range(nT)], dtype=np.int64)
-    shapes_all = [one] * nS
-    ns = [nT * HOP] * nS
+    shapes_all = ChainSchedule([one] * nS)                  # the schedule in the C ABI's form, built once
+    ns = np.full(nS, nT * HOP, dtype=np.uint32)
     r = enc.encode_chained_pac(ssl, ssr, shapes_all, num_samples=ns)                 # warm-up: buffers
     out_buf = torch.empty((int(r["total"]) + 4096,), dtype=torch.uint8, device=device)
     ts, ms = [], None
@@ -672,13 +673,15 @@ def single_stream_leg(np, torch, enc, device, hops):
     samples = 2.0 * float(shp[:, 2].sum())
     n_short = int((shp[:, 1] + shp[:, 2] != 2 * HOP).sum())
     nsmp = [int(shp[:, 2].sum())]
-    rr = enc.encode_chained_pac(both[0:1], both[1:2], [shp], num_samples=nsmp)       # warm-up
+    from mrcaudiocodec_amd import ChainSchedule
+    sched = ChainSchedule([shp])
+    rr = enc.encode_chained_pac(both[0:1], both[1:2], sched, num_samples=nsmp)       # warm-up
     out_buf = torch.empty((int(rr["total"]) + 4096,), dtype=torch.uint8, device=device)
     best, ms = None, None
     for _ in range(3):
         torch.cuda.synchronize(device)
         t0 = time.perf_counter()
-        rr = enc.encode_chained_pac(both[0:1], both[1:2], [shp], num_samples=nsmp, out=out_buf)
+        rr = enc.encode_chained_pac(both[0:1], both[1:2], sched, num_samples=nsmp, out=out_buf)
         torch.cuda.synchronize(device)
         dt = time.perf_counter() - t0
         if best is None or dt < best:

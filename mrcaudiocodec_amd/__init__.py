@@ -9,6 +9,6 @@ codecThem.py (the reference's per-block interface), batch.py (device-resident ba
 bench.py and the multi-GPU sharding), synth.py (synthetic PCM of BASELINE.md's configs).
 Importing this package needs the built shared library; running anything needs a gfx950 GPU.
 """
-from ._lib import Handle, MrcError, PinnedArray, LIB_PATH  # noqa: F401
+from ._lib import Handle, ChainSchedule, MrcError, PinnedArray, LIB_PATH  # noqa: F401
 
-__all__ = ["Handle", "MrcError", "PinnedArray", "LIB_PATH"]
+__all__ = ["Handle", "ChainSchedule", "MrcError", "PinnedArray", "LIB_PATH"]

@@ -178,6 +178,17 @@ def _p(a, typ):
     return None if a is None else a.ctypes.data_as(typ)
 
 
+class ChainSchedule:
+    """The block schedule of a chained encode as the C ABI takes it (block_start [nStreams + 1], offset / a / b per block),
+    built ONCE from per-stream shape lists or arrays and reused from call to call."""
+
+    def __init__(self, shapes):
+        self.start, self.offset, self.a, self.b = Handle._chain_schedule(shapes)
+
+    def __len__(self):
+        return len(self.start) - 1
+
+
 class Handle:
     """One mrc_handle: a device, a stream, the constant tables of the block shapes."""
 
@@ -390,6 +401,8 @@ class Handle:
     @staticmethod
     def _chain_schedule(shapes):
         """shapes[s] = [(offset, a, b), ...] (or an int array [n][3]) -> block_start, offset, a, b arrays."""
+        if isinstance(shapes, ChainSchedule):
+            return shapes.start, shapes.offset, shapes.a, shapes.b
         counts = [len(sh) for sh in shapes]
         start = np.zeros(len(shapes) + 1, np.int64)
         start[1:] = np.cumsum(counts)

@@ -131,6 +131,8 @@ class StreamEncoder:
                 raise ValueError("device-contiguous tensors expected")
         if left.dtype not in (torch.float64, torch.int16) or right.dtype != left.dtype or right.shape != left.shape:
             raise ValueError("left / right: float64 or int16 [nStreams][stride], alike")
+        if not isinstance(shapes, _lib.ChainSchedule):
+            shapes = _lib.ChainSchedule(shapes)                          # (build it once yourself if you call repeatedly)
         if len(shapes) != left.shape[0]:
             raise ValueError("one shape list per stream expected")
         if out is None:

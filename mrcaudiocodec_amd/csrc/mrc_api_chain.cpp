@@ -4,8 +4,7 @@
 //
 //   phase A   per block shape, ONE launch set over all blocks of all streams: windowed MDCT, overall scale, M/S switch,
 //             SMRs, band peaks (the batch kernels) -- nothing here depends on the bit reservoir;
-//   prep      per block: the lines of the two coded streams selected and scaled, the bit allocation's grant events sorted
-//             (chain_prep_kernel);
+//   prep      per block: the bit allocation's grant events sorted (chain_prep_kernel);
 //   phase B   one workgroup per stream walks its blocks in file order with the reservoir carried from block to block on
 //             the device (chain_phase_b_kernel): bit allocation, scale factors, mantissas, Huffman pricing;
 //   pack      per block shape plan / write kernels of the device packer around ONE prefix sum over all chunks in file
@@ -97,6 +96,9 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
     std::vector<int64_t> offs[kChainGroups];
     std::vector<long long> chunkMap[kChainGroups];
     std::vector<int32_t> resIn((size_t)n_streams, 0);
+    offs[0].reserve((size_t)nB);
+    chunkMap[0].reserve((size_t)2 * nB);
+    if (with_flush) chunkMap[4].reserve((size_t)2 * n_streams);
     {
         int64_t it = 0, ch = 0;
         for (int64_t s = 0; s < n_streams; ++s) {
@@ -142,13 +144,20 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
     int hdrLen = 0;
     std::vector<uint8_t> hdr;
     if (num_samples) {
+        // one header built by mrc_pac_header; the streams differ only in the sample count (bytes 10..13, little endian, with
+        // the reference's padding rule, pacfileThem.py:595-597: padded when it ALREADY is a multiple of nMDCTLines)
         uint8_t one[256];
         int64_t len = 0;
+        if (mrc_pac_header(&cfg, 2, num_samples[0], one, sizeof(one), &len) != MRC_OK || len < 14)
+            return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: mrc_pac_header failed");
+        hdrLen = (int)len;
+        hdr.resize((size_t)n_streams * len);
         for (int64_t s = 0; s < n_streams; ++s) {
-            if (mrc_pac_header(&cfg, 2, num_samples[s], one, sizeof(one), &len) != MRC_OK)
-                return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: mrc_pac_header failed");
-            if (s == 0) { hdrLen = (int)len; hdr.resize((size_t)n_streams * len); }
-            std::memcpy(hdr.data() + s * len, one, (size_t)len);
+            uint8_t* dst = hdr.data() + s * len;
+            std::memcpy(dst, one, (size_t)len);
+            uint32_t ns = num_samples[s];
+            if (ns % (uint32_t)cfg.n_mdct_lines == 0) ns += (uint32_t)cfg.n_mdct_lines;
+            for (int q = 0; q < 4; ++q) dst[10 + q] = (uint8_t)(ns >> (8 * q));
         }
     }
 
@@ -194,8 +203,6 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
             MRC_HIP(h, B.smr.reserve((size_t)m * nsig * S.nBands * sizeof(double)));
             MRC_HIP(h, B.peak.reserve((size_t)m * nsig * S.nBands * sizeof(double)));
             MRC_HIP(h, B.ms.reserve((size_t)m * S.nBands * sizeof(int32_t)));
-            MRC_HIP(h, B.xsel.reserve((size_t)m * nstream * S.halfN * sizeof(double)));
-            MRC_HIP(h, B.peakSel.reserve((size_t)m * nTot * sizeof(double)));
             MRC_HIP(h, B.ev.reserve((size_t)m * nEv * sizeof(unsigned)));
             MRC_HIP(h, B.pre.reserve((size_t)m * (nEv + 1) * sizeof(unsigned)));
             MRC_HIP(h, B.pos.reserve((size_t)m * nEv * sizeof(unsigned short)));
@@ -210,10 +217,9 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
                 MRC_TRY(encode_phase_a(h, S, m, pcm_left, pcm_right, sample_format, 0, B.offsets.as<int64_t>(),
                                        B.lines.as<double>(), B.oscale.as<int32_t>(), B.ms.as<int32_t>(), B.smr.as<double>(),
                                        B.peak.as<double>(), st, false));
-            MRC_HIP(h, launch_chain_prep(S, joint, m, B.lines.as<double>(), B.oscale.as<int32_t>(), B.smr.as<double>(),
-                                         B.peak.as<double>(), joint ? B.ms.as<int32_t>() : nullptr, B.xsel.as<double>(),
-                                         B.peakSel.as<double>(), B.ev.as<unsigned>(), B.pre.as<unsigned>(),
-                                         B.pos.as<unsigned short>(), h->chainForceFallback ? 1 : 0, st));
+            MRC_HIP(h, launch_chain_prep(S, joint, m, B.smr.as<double>(), joint ? B.ms.as<int32_t>() : nullptr,
+                                         B.ev.as<unsigned>(), B.pre.as<unsigned>(), B.pos.as<unsigned short>(),
+                                         h->chainForceFallback ? 1 : 0, st));
         }
         ChainGroupDev& D = desc[g];
         D.joint = joint; D.nb = S.nBands; D.nTot = nTot; D.M = S.halfN; D.K = S.maxMantBits - 1; D.nEv = nEv;
@@ -222,7 +228,8 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
         for (int v : hs[g]->bandN) if (v > D.maxN) D.maxN = v;
         D.budgetMono = S.budgetMono; D.budgetJointPre = S.budgetJointPre; D.blkswA = S.blkswA; D.blkswB = S.blkswB;
         D.bandOfLine = S.bandOfLine; D.bandN = S.bandN;
-        D.xsel = B.xsel.as<double>(); D.peakSel = B.peakSel.as<double>(); D.ev = B.ev.as<unsigned>();
+        D.lines = B.lines.as<double>(); D.peak = B.peak.as<double>(); D.oscale = B.oscale.as<int32_t>();
+        D.ms = B.ms.as<int32_t>(); D.ev = B.ev.as<unsigned>();
         D.pre = B.pre.as<unsigned>(); D.pos = B.pos.as<unsigned short>();
         D.bitAlloc = B.bitAlloc.as<int32_t>(); D.scaleFactor = B.scaleFactor.as<int32_t>();
         D.mant = B.mant.as<unsigned short>(); D.table = B.table.as<int32_t>();

@@ -59,11 +59,11 @@ constexpr int kChainGroups = 5;    // chained encode: the four joint block shape
 // the sorted grant events of the bit allocation, and the outputs of the serial scan (phase B)
 struct ChainGroupBufs {
     DevBuf offsets, lines, oscale, smr, peak, ms;                // phase A
-    DevBuf xsel, peakSel, ev, pre, pos;                          // prepared for phase B
+    DevBuf ev, pre, pos;                                         // prepared for phase B
     DevBuf bitAlloc, scaleFactor, mant, table, chunkMap;         // phase B outputs, packer inputs
     void release() {
-        for (DevBuf* b : {&offsets, &lines, &oscale, &smr, &peak, &ms, &xsel, &peakSel, &ev, &pre, &pos, &bitAlloc,
-                          &scaleFactor, &mant, &table, &chunkMap})
+        for (DevBuf* b : {&offsets, &lines, &oscale, &smr, &peak, &ms, &ev, &pre, &pos, &bitAlloc, &scaleFactor, &mant, &table,
+                          &chunkMap})
             b->release();
     }
 };

@@ -151,8 +151,10 @@ struct ChainGroupDev {               // what chain_phase_b_kernel knows about on
     double budgetMono, budgetJointPre, blkswA, blkswB;          // codecThem.py:299-308, 381-396
     const unsigned char* bandOfLine;
     const int* bandN;
-    const double* xsel;              // [n][nstream][M] lines of the coded streams, scaled by their overall scale
-    const double* peakSel;           // [n][nTot] per-band max |scaled line|
+    const double* lines;             // [n][nsig][M] unscaled MDCT lines (phase A)
+    const double* peak;              // [n][nsig][nb] per-band max |X| of the unscaled lines
+    const int* oscale;               // [n][nsig] overall scales
+    const int* ms;                   // [n][nb] M/S switch (joint groups)
     const unsigned* ev;              // [n][nEv] grant events in np.argmax's order: band | bitsAfter << 6 | nLines << 11
     const unsigned* pre;             // [n][nEv + 1] bits spent before each event if all before it are granted
     const unsigned short* pos;       // [n][K][nTot] where each band's k-th grant sits in ev
@@ -162,8 +164,7 @@ struct ChainGroupDev {               // what chain_phase_b_kernel knows about on
     int* table;                      // [n][nstream] Huffman table id (15 = raw)
 };
 size_t chain_events_per_block(const DevShape& S, int joint);
-hipError_t launch_chain_prep(const DevShape& S, int joint, int64_t nBlocks, const double* lines, const int* oscale,
-                             const double* smr, const double* peak, const int* msSwitch, double* xsel, double* peakSel,
+hipError_t launch_chain_prep(const DevShape& S, int joint, int64_t nBlocks, const double* smr, const int* msSwitch,
                              unsigned* ev, unsigned* pre, unsigned short* pos, int forceFallback, hipStream_t st);
 hipError_t launch_chain_phase_b(int64_t nStreams, const ChainGroupDev* groups, const int* items, const long long* itemStart,
                                 int* reservoir, int* resTrace, int useHuffman, int threads /* 0: chosen by stream count */,

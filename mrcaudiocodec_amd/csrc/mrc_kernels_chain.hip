@@ -6,10 +6,8 @@
 // the psychoacoustic model and the M/S decision do not (phase A: the batch kernels, one launch set per block shape over
 // ALL blocks of all streams).  This file is the rest:
 //
-//   chain_prep_kernel     per block, still reservoir-free: (a) the lines each coded stream will quantise (Mid-or-Left,
-//                         Side-or-Right per band, ms_stereo.py:70-81 / codecThem.py:524-551), scaled by their overall
-//                         scale (codecThem.py:323, exact), and the per-band peaks likewise; (b) bitalloc.py:106-155's
-//                         greedy loop unrolled into its SORTED LIST OF GRANT EVENTS.  The loop always serves the band
+//   chain_prep_kernel     per block, still reservoir-free (a wave per block): bitalloc.py:106-155's greedy loop unrolled
+//                         into its SORTED LIST OF GRANT EVENTS.  The loop always serves the band
 //                         with the largest running SMR (first index wins ties), and a band's running SMR only ever
 //                         falls (-12 for its first grant, which gives two bits, -6 per further bit): the order in which
 //                         grants are ATTEMPTED is the merge of the per-band key sequences -- independent of the budget.
@@ -36,7 +34,6 @@ namespace mrc {
 using namespace dev;
 namespace {
 
-constexpr int kChainThreads = 256;
 constexpr int kMaxEvents = 64 * 15;                   // bands (x streams) <= 64, grants per band <= maxMantBits - 1 <= 15
 constexpr int kLutSize = 65;                          // largest value in any Huffman table is 64 (index 65: any other)
 
@@ -92,71 +89,75 @@ __device__ __forceinline__ bool event_before(double ka, int ba, double kb, int b
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// prep: one workgroup per block of one shape group
+// prep: one WAVE per block of one shape group (four blocks per workgroup)
 // ------------------------------------------------------------------------------------------------------------------
 // event record: band | bitsAfter << 6 | nLines << 11 (nLines <= 2^20)
-__global__ __launch_bounds__(kChainThreads) void chain_prep_kernel(
-    DevShape S, int joint, int64_t nBlocks, const double* __restrict__ lines, const int* __restrict__ oscale,
-    const double* __restrict__ smr, const double* __restrict__ peak, const int* __restrict__ msSwitch,
-    double* __restrict__ xsel, double* __restrict__ peakSel, unsigned* __restrict__ evOut, unsigned* __restrict__ preOut,
-    unsigned short* __restrict__ posOut, int forceFallback /* tests: scramble the candidate order first */) {
-    __shared__ unsigned sEv[kMaxEvents];
-    __shared__ unsigned sPre[kMaxEvents + 1];
-    __shared__ double sKey[kMaxEvents];
-    __shared__ unsigned short sPos[kMaxEvents];
-    __shared__ double sPhi[kWave], sSmr[kWave];
-    __shared__ int sQ[kWave], sSlot[kWave];
-    __shared__ int sSig[2 * kMaxBands];                  // signal of (stream, band)
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
-    const int64_t blk = blockIdx.x;
-    const int nb = S.nBands, M = S.halfN;
+constexpr int kPrepWaves = 4;
+__global__ __launch_bounds__(kWave * kPrepWaves) void chain_prep_kernel(
+    DevShape S, int joint, int64_t nBlocks, const double* __restrict__ smr, const int* __restrict__ msSwitch,
+    unsigned* __restrict__ evOut, unsigned* __restrict__ preOut, unsigned short* __restrict__ posOut,
+    int forceFallback /* tests: scramble the candidate order first */) {
+    __shared__ unsigned sEvAll[kPrepWaves][kMaxEvents];
+    __shared__ unsigned sPreAll[kPrepWaves][kMaxEvents + 1];
+    __shared__ double sKeyAll[kPrepWaves][kMaxEvents];
+    __shared__ unsigned short sPosAll[kPrepWaves][kMaxEvents];
+    __shared__ double sPhiAll[kPrepWaves][kWave], sSmrAll[kPrepWaves][kWave];
+    __shared__ int sQAll[kPrepWaves][kWave], sSlotAll[kPrepWaves][kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t blk = (int64_t)blockIdx.x * kPrepWaves + wave;
+    if (blk >= nBlocks) return;                            // (wave-uniform; no workgroup barrier below)
+    unsigned* sEv = sEvAll[wave];
+    unsigned* sPre = sPreAll[wave];
+    double* sKey = sKeyAll[wave];
+    unsigned short* sPos = sPosAll[wave];
+    double* sPhi = sPhiAll[wave];
+    double* sSmr = sSmrAll[wave];
+    int* sQ = sQAll[wave];
+    int* sSlot = sSlotAll[wave];
+    const int nb = S.nBands;
     const int nsig = joint ? 4 : 1, nstream = joint ? 2 : 1, nTot = nstream * nb;
     const int K = S.maxMantBits - 1;
     const int nEv = nTot * K;
-    const int* osc = oscale + blk * nsig;
-    if (tid < nTot) {
-        const int band = tid % nb, strm = tid / nb;
-        const int sig = joint ? (msSwitch[blk * nb + band] ? 2 + strm : strm) : 0;   // ms_stereo.py:70-81
-        sSig[tid] = sig;
-        // codecThem.py:346-347: the band's scale factor comes from max |scaled line|; scaling by 2^overallScale is exact
-        peakSel[blk * nTot + tid] = ldexp(peak[(blk * nsig + sig) * nb + band], osc[sig]);
-    }
-    __syncthreads();
-    // (a) the lines of the coded streams, scaled
-    for (int u = tid; u < nstream * M; u += kChainThreads) {
-        const int strm = u / M, k = u - strm * M;
-        const int sig = sSig[strm * nb + S.bandOfLine[k]];
-        xsel[(blk * nstream + strm) * (int64_t)M + k] = ldexp(lines[(blk * nsig + sig) * (int64_t)M + k], osc[sig]);
-    }
-    if (wave != 0) return;
-    // (b) the sorted grant events.  lane i < nTot = (stream, band) i of bitalloc.py's concatenated arrays
-    // (codecThem.py:491-498)
+    // the sorted grant events.  lane i < nTot = (stream, band) i of bitalloc.py's concatenated arrays (codecThem.py:491-498);
+    // stream 0 = Mid-or-Left, stream 1 = Side-or-Right per band (ms_stereo.py:70-81)
     const bool valid = lane < nTot;
     double s = 0.0;
-    if (valid) s = smr[(blk * nsig + sSig[lane]) * nb + lane % nb];
+    if (valid) {
+        const int band = lane >= nb ? lane - nb : lane, strm = lane >= nb ? 1 : 0;
+        const int sig = joint ? (msSwitch[blk * nb + band] ? 2 + strm : strm) : 0;
+        s = smr[(blk * nsig + sig) * nb + band];
+    }
     {
         double qd = floor(s / 6.0);
         qd = fmin(fmax(qd, -1000000.0), 1000000.0);         // (garbage in: still a bounded, valid candidate order)
         if (!(qd == qd)) qd = 0.0;
+        double phi = s - 6.0 * qd;
+        if (!(phi == phi)) phi = 0.0;
         sQ[lane] = (int)qd;
-        sPhi[lane] = s - 6.0 * qd;
+        sPhi[lane] = phi;
         sSmr[lane] = s;
+        sSlot[lane] = 0;
     }
     wave_sync();
     // position of the band inside a 6 dB level: by SMR mod 6, larger first, equal ones by index
     int rank = 0;
     {
         const double myPhi = sPhi[lane];
-        for (int j = 0; j < nTot; ++j) {
-            const double pj = sPhi[j];
-            rank += (pj > myPhi || (pj == myPhi && j < lane)) ? 1 : 0;
+        for (int j0 = 0; j0 < nTot; j0 += 8) {              // (eight broadcast reads in flight per trip)
+            double pj[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pj[j] = sPhi[min(j0 + j, kWave - 1)];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                rank += (j0 + j < nTot && (pj[j] > myPhi || (pj[j] == myPhi && j0 + j < lane))) ? 1 : 0;
         }
     }
-    if (valid) sSlot[rank] = lane;
+    if (valid) sSlot[min(rank, kWave - 1)] = lane;
     wave_sync();
     // from here on lane r holds the band with rank r
     const int band = valid ? sSlot[lane] : 0;
-    const int nB = valid ? S.bandN[band % nb] : 0;
+    const int nB = valid ? S.bandN[band >= nb ? band - nb : band] : 0;
     const int qB = sQ[band];
     double cur = sSmr[band];                               // the band's running SMR (bitalloc.py:139,146)
     int k = 0;
@@ -185,10 +186,20 @@ __global__ __launch_bounds__(kChainThreads) void chain_prep_kernel(
     }
     if (lane == 0) sPre[nEv] = (unsigned)costBase;
     wave_sync();
-    // the candidate order against the keys themselves
+    // the candidate order against the keys themselves (reads issued together: the arrays are padded to 15 per lane)
     bool bad = false;
-    for (int p = lane; p + 1 < nEv; p += kWave)
-        bad |= !event_before(sKey[p], (int)(sEv[p] & 63u), sKey[p + 1], (int)(sEv[p + 1] & 63u));
+    {
+        double ka[kMaxEvents / kWave], kb[kMaxEvents / kWave];
+        unsigned ea[kMaxEvents / kWave], eb[kMaxEvents / kWave];
+#pragma unroll
+        for (int j = 0; j < kMaxEvents / kWave; ++j) {
+            const int p = min(lane + kWave * j, kMaxEvents - 2);
+            ka[j] = sKey[p]; kb[j] = sKey[p + 1]; ea[j] = sEv[p]; eb[j] = sEv[p + 1];
+        }
+#pragma unroll
+        for (int j = 0; j < kMaxEvents / kWave; ++j)
+            bad |= (lane + kWave * j + 1 < nEv) && !event_before(ka[j], (int)(ea[j] & 63u), kb[j], (int)(eb[j] & 63u));
+    }
     if (forceFallback) {
         // tests: exchange neighbouring events so that the repair below has real work
         wave_sync();
@@ -251,31 +262,48 @@ template <int NT> struct ChainDims {
 };
 constexpr int kEvPerLane = kMaxEvents / kWave;                                // 15
 constexpr int kMaxGrants = 15;                                                // maxMantBits - 1 <= 15
+// What a thread holds of the coming items.  Stage 1 (one item ahead): the event list, the raw band peak, the raw lines of its
+// units with the signal each comes from.  Stage 2 (two items ahead): the M/S switch of its band and an overall scale -- the
+// lines of an item can only be requested once its M/S switch says which signal each band is coded from (ms_stereo.py:70-81,
+// codecThem.py:524-551).
 template <int NT> struct ItemRegs {
     unsigned ev[ChainDims<NT>::kEvPerThread], pre[ChainDims<NT>::kEvPerThread];
     unsigned short pos[ChainDims<NT>::kEvPerThread];
     double peak;
-    int bandN;
-    double2 xa[ChainDims<NT>::kUnitsPerThread], xb[ChainDims<NT>::kUnitsPerThread];
-    unsigned bands[ChainDims<NT>::kUnitsPerThread];
+    double x[ChainDims<NT>::kUnitsPerThread][4];
+    unsigned sigs[ChainDims<NT>::kUnitsPerThread];      // signal of each of the unit's four lines, 8 bits each
 };
+struct SwitchRegs { int sig, osc; };                    // thread i < nTot: M/S switch of its band (raw); thread q < 4: scale of signal q
 // The fields of one group descriptor, held in scalar registers: they are read once per CHANGE of block shape (a stream is
 // mostly runs of long blocks), not as dependent scalar loads inside every item.  The empty asm makes each value opaque,
 // so the compiler keeps it in its register instead of loading it again from the descriptor where it is used.
-struct GroupView {
+// The pointers are declared in the GLOBAL address space: a pointer that comes out of memory is generic to the compiler, and
+// loads through it would be flat_load instructions -- which count on the LDS counter as well, so that every wait for an LDS
+// read would also wait for the prefetched loads still in flight (measured: +1.4 us per block).
+#define MRC_GLOBAL __attribute__((address_space(1)))
+typedef double double2n __attribute__((ext_vector_type(2)));       // (HIP's double2 / uint2 are classes: no address-space overloads)
+typedef unsigned uint2n __attribute__((ext_vector_type(2)));
+// Two views, so that both fit the scalar register file: what the COMPUTE of the current item reads, and what the LOADS of
+// the next items read.
+struct GroupView {                                      // compute side (current item)
     int joint, nb, nTot, M, K, nEv, maxN, nScaleBits, nstream;
     double budgetMono, budgetJointPre, blkswA, blkswB;
-    const unsigned char* bandOfLine;
-    const int* bandN;
-    const double* xsel;
-    const double* peakSel;
-    const unsigned* ev;
-    const unsigned* pre;
-    const unsigned short* pos;
-    int* bitAlloc;
-    int* scaleFactor;
-    unsigned short* mant;
-    int* table;
+    MRC_GLOBAL int* bitAlloc;
+    MRC_GLOBAL int* scaleFactor;
+    MRC_GLOBAL unsigned short* mant;
+    MRC_GLOBAL int* table;
+};
+struct LoadView {                                       // load side (next items)
+    int joint, nb, nTot, M, nEv, nstream, nsig;
+    const MRC_GLOBAL unsigned char* bandOfLine;
+    const MRC_GLOBAL int* bandN;
+    const MRC_GLOBAL double* lines;
+    const MRC_GLOBAL double* peak;
+    const MRC_GLOBAL int* oscale;
+    const MRC_GLOBAL int* ms;
+    const MRC_GLOBAL unsigned* ev;
+    const MRC_GLOBAL unsigned* pre;
+    const MRC_GLOBAL unsigned short* pos;
 };
 #define MRC_PIN(x) asm volatile("" : "+s"(x))
 __device__ __forceinline__ GroupView group_view(const ChainGroupDev* __restrict__ groups, int g) {
@@ -284,44 +312,94 @@ __device__ __forceinline__ GroupView group_view(const ChainGroupDev* __restrict_
     V.joint = D.joint; V.nb = D.nb; V.nTot = D.nTot; V.M = D.M; V.K = D.K; V.nEv = D.nEv; V.maxN = D.maxN;
     V.nScaleBits = D.nScaleBits; V.nstream = D.nstream;
     V.budgetMono = D.budgetMono; V.budgetJointPre = D.budgetJointPre; V.blkswA = D.blkswA; V.blkswB = D.blkswB;
-    V.bandOfLine = D.bandOfLine; V.bandN = D.bandN; V.xsel = D.xsel; V.peakSel = D.peakSel; V.ev = D.ev; V.pre = D.pre;
-    V.pos = D.pos; V.bitAlloc = D.bitAlloc; V.scaleFactor = D.scaleFactor; V.mant = D.mant; V.table = D.table;
+    V.bitAlloc = (MRC_GLOBAL int*)D.bitAlloc; V.scaleFactor = (MRC_GLOBAL int*)D.scaleFactor;
+    V.mant = (MRC_GLOBAL unsigned short*)D.mant; V.table = (MRC_GLOBAL int*)D.table;
     MRC_PIN(V.joint); MRC_PIN(V.nb); MRC_PIN(V.nTot); MRC_PIN(V.M); MRC_PIN(V.K); MRC_PIN(V.nEv); MRC_PIN(V.maxN);
     MRC_PIN(V.nScaleBits); MRC_PIN(V.nstream);
     MRC_PIN(V.budgetMono); MRC_PIN(V.budgetJointPre); MRC_PIN(V.blkswA); MRC_PIN(V.blkswB);
-    MRC_PIN(V.bandOfLine); MRC_PIN(V.bandN); MRC_PIN(V.xsel); MRC_PIN(V.peakSel); MRC_PIN(V.ev); MRC_PIN(V.pre);
-    MRC_PIN(V.pos); MRC_PIN(V.bitAlloc); MRC_PIN(V.scaleFactor); MRC_PIN(V.mant); MRC_PIN(V.table);
+    MRC_PIN(V.bitAlloc); MRC_PIN(V.scaleFactor); MRC_PIN(V.mant); MRC_PIN(V.table);
     return V;
 }
+__device__ __forceinline__ LoadView load_view(const ChainGroupDev* __restrict__ groups, int g) {
+    const ChainGroupDev& D = groups[g];
+    LoadView V;
+    V.joint = D.joint; V.nb = D.nb; V.nTot = D.nTot; V.M = D.M; V.nEv = D.nEv; V.nstream = D.nstream; V.nsig = D.joint ? 4 : 1;
+    V.bandOfLine = (const MRC_GLOBAL unsigned char*)D.bandOfLine; V.bandN = (const MRC_GLOBAL int*)D.bandN;
+    V.lines = (const MRC_GLOBAL double*)D.lines; V.peak = (const MRC_GLOBAL double*)D.peak;
+    V.oscale = (const MRC_GLOBAL int*)D.oscale; V.ms = (const MRC_GLOBAL int*)D.ms;
+    V.ev = (const MRC_GLOBAL unsigned*)D.ev; V.pre = (const MRC_GLOBAL unsigned*)D.pre;
+    V.pos = (const MRC_GLOBAL unsigned short*)D.pos;
+    MRC_PIN(V.joint); MRC_PIN(V.nb); MRC_PIN(V.nTot); MRC_PIN(V.M); MRC_PIN(V.nEv); MRC_PIN(V.nstream); MRC_PIN(V.nsig);
+    MRC_PIN(V.bandOfLine); MRC_PIN(V.bandN); MRC_PIN(V.lines); MRC_PIN(V.peak); MRC_PIN(V.oscale); MRC_PIN(V.ms);
+    MRC_PIN(V.ev); MRC_PIN(V.pre); MRC_PIN(V.pos);
+    return V;
+}
+// stage 2: the M/S switch of the thread's band and an overall scale, RAW -- what they mean (signal_of) is worked out when
+// they are used, an iteration later: any arithmetic on the loaded values here would make the wave wait for them, and for
+// every load of the prefetch in front of them, on the spot
+__device__ __forceinline__ SwitchRegs switch_load(const LoadView& G, int64_t idx, int tid) {
+    SwitchRegs W;
+    W.sig = 0; W.osc = 0;
+    if (tid < G.nTot && G.joint) W.sig = G.ms[idx * G.nb + (tid >= G.nb ? tid - G.nb : tid)];
+    if (tid < G.nsig) W.osc = G.oscale[idx * G.nsig + tid];
+    return W;
+}
+// ms_stereo.py:70-81: stream 0 carries Mid-or-Left, stream 1 Side-or-Right per band
+__device__ __forceinline__ int signal_of(const LoadView& G, int tid, int msRaw) {
+    return G.joint ? (msRaw ? 2 : 0) + (tid >= G.nb ? 1 : 0) : 0;
+}
+// the bands of the four lines of each of the thread's units (a function of the block shape only)
 template <int NT>
-__device__ __forceinline__ void item_load(const GroupView& G, int64_t idx, int tid, ItemRegs<NT>& R) {
+__device__ __forceinline__ void unit_bands(const LoadView& G, int tid, unsigned* bands) {
+    const int upl = G.M >> 2, nUnits = G.nstream * upl;
+#pragma unroll
+    for (int j = 0; j < ChainDims<NT>::kUnitsPerThread; ++j) {
+        const int u = tid + NT * j;
+        bands[j] = 0u;
+        if (u < nUnits) bands[j] = *(const MRC_GLOBAL unsigned*)(G.bandOfLine + 4 * (u >= upl ? u - upl : u));
+    }
+}
+// stage 1: everything else of the item; sSig = the item's signal table in LDS (written from its SwitchRegs)
+template <int NT>
+__device__ __forceinline__ void item_load(const LoadView& G, int64_t idx, int tid, const unsigned* bands,
+                                          const int* __restrict__ sSig, ItemRegs<NT>& R) {
     constexpr int kEvPerThread = ChainDims<NT>::kEvPerThread, kUnitsPerThread = ChainDims<NT>::kUnitsPerThread;
-    constexpr int kChainThreads = NT;
-    const int nEv = G.nEv, nTot = G.nTot, M = G.M, nstream = G.nstream;
-    const unsigned* ev = G.ev + idx * (int64_t)nEv;
-    const unsigned* pre = G.pre + idx * (int64_t)(nEv + 1);
-    const unsigned short* pos = G.pos + idx * (int64_t)nEv;
+    const int nEv = G.nEv, nTot = G.nTot, M = G.M, nb = G.nb;
+    const MRC_GLOBAL unsigned* ev = G.ev + idx * (int64_t)nEv;
+    const MRC_GLOBAL unsigned* pre = G.pre + idx * (int64_t)(nEv + 1);
+    const MRC_GLOBAL unsigned short* pos = G.pos + idx * (int64_t)nEv;
 #pragma unroll
     for (int j = 0; j < kEvPerThread; ++j) {
-        const int p = tid + kChainThreads * j;
+        const int p = tid + NT * j;
         R.ev[j] = p < nEv ? ev[p] : 0u;
         R.pos[j] = p < nEv ? pos[p] : (unsigned short)0;
         R.pre[j] = p <= nEv ? pre[p] : 0u;
     }
-    R.peak = tid < nTot ? G.peakSel[idx * nTot + tid] : 0.0;
-    R.bandN = tid < nTot ? G.bandN[tid >= G.nb ? tid - G.nb : tid] : 0;
-    const int upl = M >> 2, nUnits = nstream * upl;
+    R.peak = 0.0;
+    if (tid < nTot) R.peak = G.peak[(idx * G.nsig + sSig[tid]) * nb + (tid >= nb ? tid - nb : tid)];
+    const int upl = M >> 2, nUnits = G.nstream * upl;
+    const MRC_GLOBAL double* blockLines = G.lines + idx * G.nsig * (int64_t)M;
 #pragma unroll
     for (int j = 0; j < kUnitsPerThread; ++j) {
-        const int u = tid + kChainThreads * j;
-        R.xa[j] = make_double2(0.0, 0.0); R.xb[j] = make_double2(0.0, 0.0); R.bands[j] = 0u;
+        const int u = tid + NT * j;
+        R.sigs[j] = 0u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) R.x[j][q] = 0.0;
         if (u < nUnits) {
             const int strm = u >= upl ? 1 : 0;
             const int k = 4 * (u - strm * upl);
-            const double* src = G.xsel + (idx * nstream + strm) * (int64_t)M + k;
-            R.xa[j] = *reinterpret_cast<const double2*>(src);
-            R.xb[j] = *reinterpret_cast<const double2*>(src + 2);
-            R.bands[j] = *reinterpret_cast<const unsigned*>(G.bandOfLine + k);
+            unsigned sg = 0u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sg |= (unsigned)sSig[strm * nb + (int)((bands[j] >> (8 * q)) & 0xffu)] << (8 * q);
+            R.sigs[j] = sg;
+            if (sg == (sg & 0xffu) * 0x01010101u) {        // one signal for the four lines (nearly always): two 16-byte loads
+                const MRC_GLOBAL double* src = blockLines + (int64_t)(sg & 0xffu) * M + k;
+                const double2n a = *(const MRC_GLOBAL double2n*)src, b = *(const MRC_GLOBAL double2n*)(src + 2);
+                R.x[j][0] = a.x; R.x[j][1] = a.y; R.x[j][2] = b.x; R.x[j][3] = b.y;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) R.x[j][q] = blockLines[(int64_t)((sg >> (8 * q)) & 0xffu) * M + k + q];
+            }
         }
     }
 }
@@ -357,13 +435,15 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
     __shared__ unsigned sEv[kMaxEvents + kChainThreads];
     __shared__ unsigned sPre[kMaxEvents + kChainThreads];
     __shared__ unsigned short sPos[kMaxEvents + kChainThreads];
-    __shared__ double sPeak[kWave];
-    __shared__ int sBandN[kWave];
+    __shared__ double sPeak[kWave];                      // raw max |X| of the (stream, band)'s signal
+    __shared__ int sSig[2][kWave];                       // signal of (stream, band) i: this item's / the next item's (by parity)
+    __shared__ int sOsc[2][4];                           // overall scale of signal q, likewise
     __shared__ unsigned sInfo[kWave];                    // per (stream, band): bits | scale factor << 8
     __shared__ unsigned sEsc[kWave];                     // per (stream, band): bits + escape code length of each table, 8 bits each
     __shared__ unsigned sLut[kLutSize + 1];              // per value: the four code lengths, 8 bits each (0: not in the table)
     __shared__ unsigned sRed[kChainThreads / kWave][4];
     __shared__ int sCtl[4];                              // remaining bits, raw bits of stream 0 / 1, reservoir
+    __shared__ int sItems[256];                          // ring of item ids (see below)
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const int64_t strmId = blockIdx.x;
     for (int v = tid; v <= kLutSize; v += kChainThreads) {
@@ -377,16 +457,55 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
     if (tid == 0) sCtl[3] = reservoir[strmId];
     const long long i0 = itemStart[strmId], i1 = itemStart[strmId + 1];
     ItemRegs<NT> R;
-    int itemCur = 0, itemNext = 0;
-    GroupView G = group_view(groups, 0), Gn = G;         // the current item's group, the next item's
-    int gOfG = 0, gOfGn = 0;
+    SwitchRegs W;                                        // the NEXT item's switch and scales
+    W.sig = 0; W.osc = 0;
+    unsigned bandsCur[kUnitsPerThread], bandsNext[kUnitsPerThread];   // bands of the thread's lines: current / next block shape
+    int nCur = 0, nNext = 0;                             // lines of the thread's (stream, band)
+    int itemCur = 0, itemNext = 0, itemAfter = 0;
+    GroupView G = group_view(groups, 0);                 // the current item's group (compute side)
+    LoadView Ln = load_view(groups, 0);                  // the next item's group (load side)
+    int gOfG = 0, gOfLn = 0;
+    auto band_size = [&](const LoadView& V) { return tid < V.nTot ? (int)V.bandN[tid >= V.nb ? tid - V.nb : tid] : 0; };
+    // The stream's item ids sit in an LDS ring of two halves of 128, refilled half by half (once per 128 items, by a
+    // load whose result is used inside the refill branch only).  A scalar load in the loop would share its counter with the
+    // LDS reads -- every LDS wait would also wait for it -- and a vector load whose result is picked up iterations later
+    // makes the compiler wait for ALL outstanding vector memory operations, the previous item's stores included, every
+    // iteration.
+    constexpr int kIdHalf = 128;
+    auto fill_ids = [&](long long chunk) {                // ids [i0 + 128 chunk, + 128) -> half (chunk & 1)
+        if (tid < kIdHalf) {
+            const long long i = i0 + chunk * kIdHalf + tid;
+            sItems[(int)(chunk & 1) * kIdHalf + tid] = i < i1 ? items[i] : 0;
+        }
+    };
+    fill_ids(0);
+    fill_ids(1);
+    __syncthreads();
+    auto item_id = [&](long long i) {                     // (uniform) i inside the two chunks held
+        return __builtin_amdgcn_readfirstlane(sItems[(int)((i - i0) & (2 * kIdHalf - 1))]);
+    };
     if (i0 < i1) {
-        itemCur = items[i0];
-        itemNext = i0 + 1 < i1 ? items[i0 + 1] : 0;
+        itemCur = item_id(i0);
+        itemNext = i0 + 1 < i1 ? item_id(i0 + 1) : 0;
+        itemAfter = i0 + 2 < i1 ? item_id(i0 + 2) : 0;
         gOfG = (int)((unsigned)itemCur >> 28);
-        if (gOfG != 0) G = group_view(groups, gOfG);
-        Gn = G; gOfGn = gOfG;
-        item_load(G, itemCur & 0x0fffffff, tid, R);
+        if (gOfG != 0) { G = group_view(groups, gOfG); Ln = load_view(groups, gOfG); }
+        gOfLn = gOfG;
+        const SwitchRegs W0 = switch_load(Ln, itemCur & 0x0fffffff, tid);
+        if (tid < kWave) sSig[0][tid] = signal_of(Ln, tid, W0.sig);
+        if (tid < 4) sOsc[0][tid] = W0.osc;
+        unit_bands<NT>(Ln, tid, bandsCur);
+        nCur = band_size(Ln);
+        __syncthreads();
+        item_load<NT>(Ln, itemCur & 0x0fffffff, tid, bandsCur, sSig[0], R);
+#pragma unroll
+        for (int j = 0; j < kUnitsPerThread; ++j) bandsNext[j] = bandsCur[j];
+        nNext = nCur;
+        if (i0 + 1 < i1) {
+            const int gn = (int)((unsigned)itemNext >> 28);
+            if (gn != gOfLn) { Ln = load_view(groups, gn); gOfLn = gn; unit_bands<NT>(Ln, tid, bandsNext); nNext = band_size(Ln); }
+            W = switch_load(Ln, itemNext & 0x0fffffff, tid);
+        }
     }
     __syncthreads();
 #ifdef MRC_CHAIN_PROFILE
@@ -397,26 +516,43 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
         const int64_t idx = item & 0x0fffffff;
         const int nb = G.nb, nTot = G.nTot, M = G.M, K = G.K, nEv = G.nEv, nstream = G.nstream;
         MRC_CP(0);
-        // ---- this item's event list, peaks and band sizes: registers -> LDS; its lines stay in registers
+        // ---- this item's event list and peaks: registers -> LDS (its lines stay in registers); the next item's switch
+        //      and scales: registers -> the other half of the signal tables
+        const int par = (int)((it - i0) & 1);
 #pragma unroll
         for (int j = 0; j < kEvPerThread; ++j) {
             const int p = tid + kChainThreads * j;
             sEv[p] = R.ev[j]; sPre[p] = R.pre[j]; sPos[p] = R.pos[j];
         }
-        if (tid < kWave) { sPeak[tid] = R.peak; sBandN[tid] = R.bandN; }
-        double2 xa[kUnitsPerThread], xb[kUnitsPerThread];
-        unsigned bandsOf[kUnitsPerThread];
+        if (tid < kWave) { sPeak[tid] = R.peak; sSig[par ^ 1][tid] = signal_of(Ln, tid, W.sig); }
+        if (tid < 4) sOsc[par ^ 1][tid] = W.osc;
+        double xr[kUnitsPerThread][4];
+        unsigned sigsOf[kUnitsPerThread];
 #pragma unroll
-        for (int j = 0; j < kUnitsPerThread; ++j) { xa[j] = R.xa[j]; xb[j] = R.xb[j]; bandsOf[j] = R.bands[j]; }
+        for (int j = 0; j < kUnitsPerThread; ++j) {
+            sigsOf[j] = R.sigs[j];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) xr[j][q] = R.x[j][q];
+        }
         MRC_CP(1);
         __syncthreads();
         MRC_CP(2);
-        // ---- the next item's loads go out now and land while this one is computed (its id came with the previous one)
-        const int itemAfter = it + 2 < i1 ? items[it + 2] : 0;
-        if (it + 1 < i1) {
-            const int gn = (int)((unsigned)itemNext >> 28);
-            if (gn != gOfGn) { Gn = group_view(groups, gn); gOfGn = gn; }    // (a change of block shape: rare)
-            item_load(Gn, itemNext & 0x0fffffff, tid, R);
+        // ---- the next item's loads go out now and land while this one is computed; and the switch of the item after it
+        // (ids up to it + 3 are read here; a chunk is replaced when the scan is 8 items into the NEXT one: everything of the
+        // old chunk has been read, and the new ids are visible after this iteration's barriers, 117 items before their turn)
+        if (((it - i0) & (kIdHalf - 1)) == 8 && it - i0 >= kIdHalf) fill_ids((it - i0) / kIdHalf + 1);
+        const int itemAfter2 = it + 3 < i1 ? item_id(it + 3) : 0;
+        if (it + 1 < i1) item_load<NT>(Ln, itemNext & 0x0fffffff, tid, bandsNext, sSig[par ^ 1], R);
+        const int gAfter = (int)((unsigned)itemAfter >> 28);
+        if (it + 2 < i1) {
+            if (gAfter == gOfLn) {
+                W = switch_load(Ln, itemAfter & 0x0fffffff, tid);
+            } else {                                                            // (a change of block shape: rare)
+                W = switch_load(load_view(groups, gAfter), itemAfter & 0x0fffffff, tid);
+                // the values are waited for HERE: a load still pending at the end of a rare path would make the compiler
+                // guard the code behind the merge with a wait for all vector memory operations, on every iteration
+                asm volatile("" : "+v"(W.sig), "+v"(W.osc));
+            }
         }
         MRC_CP(3);
         if (wave == 0) {
@@ -446,7 +582,7 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
 #pragma unroll
             for (int k = 0; k < kMaxGrants; ++k) c += ((k < K) & (posV[k] < cut)) ? 1 : 0;
             int myBits = (valid && c) ? c + 1 : 0;                         // the first grant gives two bits
-            const int myN = valid ? sBandN[lane] : 0;
+            const int myN = valid ? nCur : 0;
             int spent = (int)sPre[cut];
             MRC_CP(4);
             // The tail, in batches: the next 64 events at a time.  A band that no longer fits can never be granted again
@@ -494,7 +630,9 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
             const int raw0 = wave_sum_i((valid && lane < nb) ? rawMine : 0);
             const int raw1 = wave_sum_i((valid && lane >= nb) ? rawMine : 0);
             if (valid) {
-                const int sf = scale_factor32(sPeak[lane], G.nScaleBits, myBits);
+                // codecThem.py:346-347: the scale factor comes from max |scaled line| of the band; scaling by 2^overallScale
+                // is exact, so maximum and scaling commute
+                const int sf = scale_factor32(ldexp(sPeak[lane], sOsc[par][sSig[par][lane]]), G.nScaleBits, myBits);
                 sInfo[lane] = (unsigned)myBits | ((unsigned)sf << 8);
                 sEsc[lane] = escLen4 + (unsigned)myBits * 0x01010101u;
                 G.bitAlloc[idx * nTot + lane] = myBits;
@@ -522,8 +660,10 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
                 if (u < nUnits) {
                     const int strm = u >= upl ? 1 : 0;
                     const int k = 4 * (u - strm * upl);
-                    const unsigned bands = bandsOf[jj];
-                    const double x[4] = {xa[jj].x, xa[jj].y, xb[jj].x, xb[jj].y};
+                    const unsigned bands = bandsCur[jj];
+                    double x[4];                                           // codecThem.py:323: X * 2^overallScale (exact)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[q] = ldexp(xr[jj][q], sOsc[par][(sigsOf[jj] >> (8 * q)) & 0xffu]);
                     unsigned code[4], acc = 0u;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -544,10 +684,10 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
                         code[j] = cdv;
                     }
                     if (strm) accB += acc; else accA += acc;
-                    uint2 w;
+                    uint2n w;
                     w.x = code[0] | (code[1] << 16);
                     w.y = code[2] | (code[3] << 16);
-                    *reinterpret_cast<uint2*>(G.mant + (idx * nstream + strm) * (int64_t)M + k) = w;
+                    *(MRC_GLOBAL uint2n*)(G.mant + (idx * nstream + strm) * (int64_t)M + k) = w;
                 }
             }
         }
@@ -589,7 +729,19 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
         }
         itemCur = itemNext;
         itemNext = itemAfter;
-        G = Gn; gOfG = gOfGn;
+        itemAfter = itemAfter2;
+#pragma unroll
+        for (int j = 0; j < kUnitsPerThread; ++j) bandsCur[j] = bandsNext[j];
+        nCur = nNext;
+        if (it + 1 < i1 && gOfLn != gOfG) { G = group_view(groups, gOfLn); gOfG = gOfLn; }     // (changes of block shape: rare)
+        if (it + 2 < i1 && gAfter != gOfLn) {
+            Ln = load_view(groups, gAfter); gOfLn = gAfter;
+            unit_bands<NT>(Ln, tid, bandsNext);
+            nNext = band_size(Ln);
+#pragma unroll
+            for (int j = 0; j < kUnitsPerThread; ++j) asm volatile("" : "+v"(bandsNext[j]));     // (waited for here, see above)
+            asm volatile("" : "+v"(nNext));
+        }
         MRC_CP(10);
         __syncthreads();
         MRC_CP(11);
@@ -633,12 +785,11 @@ extern "C" int mrc_debug_chain_profile(unsigned long long* out /*[16]*/, int res
 
 size_t chain_events_per_block(const DevShape& S, int joint) { return (size_t)(joint ? 2 : 1) * S.nBands * (S.maxMantBits - 1); }
 
-hipError_t launch_chain_prep(const DevShape& S, int joint, int64_t nBlocks, const double* lines, const int* oscale,
-                             const double* smr, const double* peak, const int* msSwitch, double* xsel, double* peakSel,
+hipError_t launch_chain_prep(const DevShape& S, int joint, int64_t nBlocks, const double* smr, const int* msSwitch,
                              unsigned* ev, unsigned* pre, unsigned short* pos, int forceFallback, hipStream_t st) {
     if (nBlocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(chain_prep_kernel, dim3((unsigned)nBlocks), dim3(kChainThreads), 0, st, S, joint, nBlocks, lines,
-                       oscale, smr, peak, msSwitch, xsel, peakSel, ev, pre, pos, forceFallback);
+    hipLaunchKernelGGL(chain_prep_kernel, dim3((unsigned)((nBlocks + kPrepWaves - 1) / kPrepWaves)), dim3(kWave * kPrepWaves),
+                       0, st, S, joint, nBlocks, smr, msSwitch, ev, pre, pos, forceFallback);
     return hipGetLastError();
 }
 

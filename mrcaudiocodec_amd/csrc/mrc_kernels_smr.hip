@@ -338,6 +338,30 @@ __device__ __forceinline__ void mfma_terms(double4v& D, double t, double da, int
 }
 #endif
 
+// 1/x for a finite positive normal x: hardware estimate + two Newton steps (relative error ~2^-52; NOT the correctly
+// rounded quotient -- used by the fast spreading mode only, where one more rounding per masker / line is inside what the
+// FFT in front of it already differs from the reference's by; the EXACT mode divides like the reference)
+__device__ __forceinline__ double recip_nr(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+// atan(x) for x >= 0 (psychoac.py:27-29's two calls per masker), <= 2 ulp: x <= 1: x Q(x^2), Q of degree 21 from a
+// Chebyshev fit in 60-digit arithmetic (tools/make_atan_poly.py); x > 1: pi/2 - atan(1/x).  ~40 instructions against the
+// ~90 of the library's.
+// atan(t) = t * Q(t^2), 0 <= t <= 1; Q of degree 21 (tools/make_atan_poly.py)
+__device__ constexpr double kAtanQ[22] = {0x1.0000000000000p+0, -0x1.5555555555546p-2, 0x1.999999999861ep-3, -0x1.2492492443a94p-3, 0x1.c71c71b1fed92p-4, -0x1.745d1586bfed2p-4, 0x1.3b1398601e89dp-4, -0x1.1110151cb4f09p-4, 0x1.e1d315290f292p-5, -0x1.aed3667a4693ap-5, 0x1.849ab97c0d9e6p-5, -0x1.5eda2e1403e06p-5, 0x1.385c01bcb507ap-5, -0x1.0b657ae92d3e9p-5, 0x1.a91e0c9b2881ep-6, -0x1.2d3ffbb3d4964p-6, 0x1.6c7238a2d8193p-7, -0x1.6773524f49226p-8, 0x1.12060552e1b82p-9, -0x1.2c4eeb1fa7a5bp-11, 0x1.a2865ec94274cp-14, -0x1.156d8b1441eeep-17};
+__device__ __forceinline__ double atan_pos(double x) {
+    const bool big = x > 1.0;
+    const double t = big ? recip_nr(x) : x;
+    const double u = t * t;
+    double q = kAtanQ[21];
+#pragma unroll
+    for (int i = 20; i >= 0; --i) q = fma(q, u, kAtanQ[i]);
+    const double a = t * q;
+    return big ? (0x1.921fb54442d18p+0 - a) + 0x1.1a62633145c07p-54 : a;
+}
+
 // kLog10Tab as [j][4] for the LDS copy
 struct LogTabDev { double v[kLogTabEntries * 4]; };
 constexpr LogTabDev make_log_tab() {
@@ -666,11 +690,14 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
         {
             double s3 = (x0 + x1) + x2;
             double level = EXACT ? spl_db(s3) : spl_db_tab(s3, logTab);      // psychoac.py:164
-            double fm = S.binHz * (((p - 1) * x0 + p * x1) + (p + 1) * x2) / s3;   // psychoac.py:165
+            const double fnum = S.binHz * (((p - 1) * x0 + p * x1) + (p + 1) * x2);
+            double fm = EXACT ? fnum / s3 : fnum * recip_nr(s3);                  // psychoac.py:165
             // psychoac.py:27-29.  The fast path multiplies by the reciprocals of the constants 7500, 1000 and 10
-            // (one rounding more each, against ~12 instructions per fp64 division); EXACT divides like the reference
+            // (one rounding more each, against ~12 instructions per fp64 division) and uses atan_pos; EXACT divides and
+            // calls atan like the reference
             double q = EXACT ? fm / 7500. : fm * (1. / 7500.);
-            const double zm = 13 * atan(EXACT ? 0.76 * fm / 1000. : (0.76 * fm) * 1e-3) + 3.5 * atan(q * q);
+            const double zm = EXACT ? 13 * atan(0.76 * fm / 1000.) + 3.5 * atan(q * q)
+                                    : 13 * atan_pos((0.76 * fm) * 1e-3) + 3.5 * atan_pos(q * q);
             const double lvl15 = level - 15.0;                               // psychoac.py:42-43 (tonal drop)
             const double boost = 0.37 * fmax(level - 40, 0.0);               // psychoac.py:76
             double* e = mt + 4 * before;
@@ -1093,7 +1120,7 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
                 ex = excess_plain(t, a2, scale, logTab, &thr);
                 if (thresh && k < M) thresh[(int64_t)unit * M + k] = thr;
             } else {
-                q = a2 / t;
+                q = a2 * recip_nr(t);
             }
             const int bnd = cur.bnd;                     // lanes past the end repeat the last line: maxima unchanged
             if (__all(bnd == __builtin_amdgcn_readfirstlane(bnd))) {

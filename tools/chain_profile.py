@@ -28,7 +28,7 @@ raw.mrc_debug_chain_profile(prof, 1)
 h.encode_chained_pac(pcm[0][None], pcm[1][None], [shapes], num_samples=[hops * 1024])
 raw.mrc_debug_chain_profile(prof, 1)
 n = len(shapes) + 2
-names = ["loop top (item fetch)", "regs -> LDS", "barrier 1", "issue next loads", "alloc head (cut, bits)", "alloc tail walk",
+names = ["loop top", "regs -> LDS", "barrier 1", "issue next loads", "alloc head (cut, bits)", "alloc tail (batches)",
          "scale factors", "barrier 2", "quantise + price + wave sums", "barrier 3", "decision (thread 0)", "barrier 4"]
 v = list(prof)
 out = {"blocks": n, "cycles_per_block": {names[i]: v[i] / n for i in range(12)}, "total_cycles_per_block": sum(v[:12]) / n,
