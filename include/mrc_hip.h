@@ -437,6 +437,7 @@ int mrc_set_timing(mrc_handle* h, int enabled);
  * serial scan (default 0: 512 for up to 512 streams -- the latency of the one stream counts -- else 256: eight streams per CU). */
 #define MRC_OPT_CHAIN_THREADS 4
 int mrc_set_option(mrc_handle* h, int option, int value);
+int mrc_get_option(mrc_handle* h, int option, int32_t* value);
 int mrc_get_stage_ms(mrc_handle* h, double* ms /*[3]*/);
 /* ... and per kernel: ms[0..4] = MDCT, smr_kernel, band_stats_kernel (joint only, else ~0), bitalloc_kernel,
  * quantize_kernel. */

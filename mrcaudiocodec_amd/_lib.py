@@ -26,7 +26,8 @@ class MrcConfig(C.Structure):
 
 
 class MrcError(RuntimeError):
-    pass
+    """code: the mrc_status the library returned (None for errors raised by the binding itself)"""
+    code = None
 
 
 def _preload_hip_runtime():
@@ -144,6 +145,7 @@ def _load():
                                             _i32p, _i32p, _i32p, _u8p, C.c_int64, _i64p, _i32p, _i32p]),
         "mrc_set_timing": (C.c_int, [H, C.c_int]),
         "mrc_set_option": (C.c_int, [H, C.c_int, C.c_int]),
+        "mrc_get_option": (C.c_int, [H, C.c_int, _i32p]),
         "mrc_get_stage_ms": (C.c_int, [H, _f64p]),
     }
     for name, (res, args) in sig.items():
@@ -228,7 +230,9 @@ class Handle:
     def _check(self, rc):
         if rc != 0:
             msg = lib.mrc_last_error(self._h)
-            raise MrcError("libmrc_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+            err = MrcError("libmrc_hip error %d: %s" % (rc, msg.decode() if msg else "?"))
+            err.code = rc
+            raise err
 
     # ---- shape queries
     def bands(self, a, b):
@@ -687,6 +691,11 @@ class Handle:
 
     def set_option(self, option, value):
         self._check(lib.mrc_set_option(self._h, int(option), int(value)))
+
+    def get_option(self, option):
+        v = C.c_int32()
+        self._check(lib.mrc_get_option(self._h, int(option), C.byref(v)))
+        return v.value
 
     def set_timing(self, on):
         self._check(lib.mrc_set_timing(self._h, int(bool(on))))

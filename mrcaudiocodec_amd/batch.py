@@ -98,11 +98,14 @@ class StreamEncoder:
                                                _ptr(out["bit_alloc"]), _ptr(out["mantissa"]), m16, _ptr(buf), cap, _ptr(offs),
                                                _ptr(table), _ptr(saved), True, stream)
                 break
-            except _lib.MrcError:
-                if attempt or cap >= n * ns * bound:
+            except _lib.MrcError as e:
+                # only "buffer too small" is worth a second attempt at the worst-case size; a bad table id or a HIP error is not
+                if attempt or cap >= n * ns * bound or getattr(e, "code", None) != _lib.MRC_ERR_NOMEM:
                     raise
                 cap = n * ns * bound
-        return {"bytes": buf[:total], "block_offset": offs, "huff_table": table, "bits_saved": saved}
+        # with the tables GIVEN nothing is priced here: no bits_saved (mirrors pacfile._pack)
+        return {"bytes": buf[:total], "block_offset": offs, "huff_table": table,
+                "bits_saved": None if huff_table is not None else saved}
 
     def huffman_gain(self, a, b, out, use_huffman=True):
         """Prices the Huffman tables for the blocks in `out` (a dict from encode) on the device and returns

@@ -65,6 +65,7 @@ def encode_wav(in_path, out_path=None, use_huffman=True, device_id=0, handle=Non
     if n_ch != 2:
         raise ValueError("stereo input only (the reference's JointEncode indexes data[0], data[1])")
     h = handle if handle is not None else Handle(sample_rate=rate, device_id=device_id)
+    was_exact = h.get_option(1)
     if exact_spread:
         h.set_option(1, 1)
     try:
@@ -81,7 +82,7 @@ def encode_wav(in_path, out_path=None, use_huffman=True, device_id=0, handle=Non
         data = r["bytes"].tobytes()
     finally:
         if exact_spread and handle is not None:
-            h.set_option(1, 0)                   # (a caller's handle gets back the default it came with only if WE changed it)
+            h.set_option(1, was_exact)           # (a caller's handle gets back the setting it came with)
         if handle is None:
             h.close()
     if out_path:

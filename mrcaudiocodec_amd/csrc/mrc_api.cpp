@@ -158,6 +158,17 @@ int mrc_set_option(mrc_handle* h, int option, int value) {
     return fail(h, MRC_ERR_INVALID, "mrc_set_option: unknown option");
 }
 
+int mrc_get_option(mrc_handle* h, int option, int32_t* value) {
+    if (!h || !value) return MRC_ERR_INVALID;
+    switch (option) {
+        case MRC_OPT_EXACT_SPREAD: *value = h->exactSpread ? 1 : 0; return MRC_OK;
+        case MRC_OPT_SMR_ALL_BANDS: *value = h->smrAllBands ? 1 : 0; return MRC_OK;
+        case MRC_OPT_CHAIN_FORCE_REPAIR: *value = h->chainForceFallback ? 1 : 0; return MRC_OK;
+        case MRC_OPT_CHAIN_THREADS: *value = h->chainThreads; return MRC_OK;
+        default: return fail(h, MRC_ERR_INVALID, "mrc_get_option: unknown option");
+    }
+}
+
 int mrc_get_stage_ms(mrc_handle* h, double* ms) {
     if (!h || !ms) return MRC_ERR_INVALID;
     for (int i = 0; i < 3; ++i) ms[i] = h->stageMs[i];
@@ -340,7 +351,7 @@ int encode_phase_a(mrc_handle* h, const DevShape& S, int64_t n, const void* chL,
     if (timing) MRC_HIP(h, hipEventRecord(h->ev[1], st));
     if (joint)
         MRC_HIP(h, launch_ms_switch(n, S.nBands, S.msLeaves, S.msInternal, S.msPlan, lines, lines + S.halfN,
-                                    4 * (int64_t)S.halfN, msSwitch, st));
+                                    4 * (int64_t)S.halfN, S.halfN, msSwitch, st));
     if (timing) MRC_HIP(h, hipEventRecord(h->ev[2], st));
     MRC_HIP(h, launch_smr(S, n, chL, chR, fmt, stride, offsets, lines, oscale, smr, nullptr, peak,
                           (joint && !h->smrAllBands) ? msSwitch : nullptr, h->exactSpread, st));
@@ -1179,7 +1190,7 @@ int mrc_ms_switch(mrc_handle* h, int64_t n_blocks, int n_bands, const int32_t* n
     MRC_TRY(s.up(h->inR, lines_right, (size_t)n_blocks * total * sizeof(double)));
     MRC_HIP(h, h->outC.reserve((size_t)n_blocks * n_bands * sizeof(int32_t)));
     MRC_HIP(h, launch_ms_switch(n_blocks, n_bands, nLeaves, nInternal, h->inAux.as<int>(), h->inL.as<double>(),
-                                h->inR.as<double>(), total, h->outC.as<int>(), h->stream));
+                                h->inR.as<double>(), total, total, h->outC.as<int>(), h->stream));
     MRC_TRY(s.down(ms_switch, h->outC, (size_t)n_blocks * n_bands * sizeof(int32_t)));
     MRC_HIP(h, hipStreamSynchronize(h->stream));
     return MRC_OK;

@@ -189,7 +189,7 @@ hipError_t launch_transient_peaks(int64_t nHops, int nCh, int hop, int nShort, i
 hipError_t launch_stereo_masking(int64_t n, const double* mid, const double* side, const double* z, double* outMid,
                                  double* outSide, hipStream_t st);
 hipError_t launch_ms_switch(int64_t nBlocks, int nBands, int nLeaves, int nInternal, const int* plan /* device */,
-                            const double* L, const double* R, int64_t blockStride /* doubles between blocks */, int* out,
-                            hipStream_t st);
+                            const double* L, const double* R, int64_t blockStride /* doubles between blocks */,
+                            int nLines /* lines per block */, int* out, hipStream_t st);
 
 }  // namespace mrc

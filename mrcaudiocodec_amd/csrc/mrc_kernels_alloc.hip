@@ -340,7 +340,7 @@ hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, con
                            bandPeakWs);
     if (joint && !msReady) {                             // on the UNSCALED L / R lines (codecThem.py:436)
         hipError_t e = launch_ms_switch(nFrames, S.nBands, S.msLeaves, S.msInternal, S.msPlan, lines, lines + S.halfN,
-                                        4 * (int64_t)S.halfN, msSwitch, st);
+                                        4 * (int64_t)S.halfN, S.halfN, msSwitch, st);
         if (e != hipSuccess) return e;
     }
     if (ev) (void)hipEventRecord(ev[0], st);

@@ -149,3 +149,4 @@ def test_argument_checks(h):
         h.encode_chained_pac(stream[0][None], stream[1][None], [[(0, 512, 512)]])
     with pytest.raises(MrcError):                                       # Close() needs a long last block
         h.encode_chained_pac(stream[0][None], stream[1][None], [[(0, 1024, 128)]], with_flush=True)
+

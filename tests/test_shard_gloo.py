@@ -94,3 +94,62 @@ def test_bench_stream_generator_shards_are_slices_of_one_stream():
                 for ch in range(len(whole)):
                     assert torch.equal(part[ch], whole[ch][lo:hi]), (kind, world, rank)
     assert not whole[0][:1024].any() and whole[0].dtype == torch.int16
+
+
+# ------------------------------------------------------------------ chained (stream) mode: whole streams per rank
+def _stream_corpus():
+    from mrcaudiocodec_amd import synth
+    hops = 5
+    tone = synth.c1_sine(hops)
+    g = synth.c2_noise(hops, seed=3, sigma=0.05)
+    x, sh_sw = synth.c4_transients(hops + 1)
+    sh_long = [(i * 1024, 1024, 1024) for i in range(hops - 1)]
+    n = len(tone)
+    streams = np.stack([np.stack([tone, 0.9 * tone]), np.stack([0.5 * tone + g, 0.5 * tone - g]), np.stack([g, 0.2 * tone])])
+    return streams, [sh_long[:2], sh_long[:3], sh_long[:2]], n
+
+
+def _stream_worker(rank, world, port, out_dir):
+    import pickle
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pacfile as opac
+    streams, shapes, _ = _stream_corpus()
+    first, count = shard.shard_streams(len(shapes), world, rank)
+    mine = [opac.encode_stereo_stream(streams[s], shapes[s], huffman=True) for s in range(first, first + count)]   # the checker
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (first, mine))             # (result collection only: nothing on the data path)
+    if rank == 0:
+        with open(os.path.join(out_dir, "all.pkl"), "wb") as f:
+            pickle.dump(gathered, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_stream_sharded_chained_mode(tmp_path):
+    # whole streams per rank (a stream is serial through its reservoir); the ranks' lists, in rank order, are the
+    # single-process result.  The encoder here is the oracle: what is tested is the partition and the rank plumbing
+    # (the GPU form of the same test: tests/test_gpu_chain.py::test_two_processes_share_the_streams)
+    pytest.importorskip("torch")
+    import pickle
+    import torch.multiprocessing as mp
+    from oracle import pacfile as opac
+    world = 2
+    mp.spawn(_stream_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    with open(os.path.join(str(tmp_path), "all.pkl"), "rb") as f:          # (written by this test's own workers)
+        gathered = pickle.load(f)
+    streams, shapes, _ = _stream_corpus()
+    assert [g[0] for g in gathered] == [0, 2]
+    got = [b for _, part in gathered for b in part]
+    assert len(got) == len(shapes)
+    for s in range(len(shapes)):
+        assert got[s] == opac.encode_stereo_stream(streams[s], shapes[s], huffman=True), s
+
+
+def test_stream_shards_cover_exactly():
+    for n in (0, 1, 5, 8192):
+        for world in (1, 2, 8):
+            got = [shard.shard_streams(n, world, r) for r in range(world)]
+            assert got[0][0] == 0 and sum(c for _, c in got) == n
