@@ -302,3 +302,68 @@ def test_pac_stream_structure():
         pos += 4 + n
         chunks += 1
     assert pos == len(data) and chunks == 2 * (3 + 1)
+
+
+# ------------------------------------------------------------------ the chained encode's bit allocation, as a model
+def _alloc_by_event_list(budget, max_mant, n_lines, smr):
+    """The scheme of csrc/mrc_kernels_chain.hip restated in plain Python: the grant ATTEMPTS of bitalloc.py:106-155 in the
+    order np.argmax serves them (keys S, S-12, S-18, ... per band, ties by band), their cost prefix sums, a cut where fewer
+    than max(nLines) bits would be left, then the tail event by event with immediate retirement of bands that no longer
+    fit; integer budget tests (nLines <= left <=> nLines + spent <= floor(budget); left > 0 <=> spent < ceil(budget))."""
+    import math
+    n_tot, K = len(smr), max_mant - 1
+    evs = []
+    for i in range(n_tot):
+        cur = float(smr[i])
+        for k in range(K):
+            evs.append((cur, i, k))
+            cur = cur - 12.0 if k == 0 else cur - 6.0
+    evs.sort(key=lambda t: (-t[0], t[1]))
+    pre = [0]
+    for (_, i, k) in evs:
+        pre.append(pre[-1] + (2 * n_lines[i] if k == 0 else n_lines[i]))
+    bf, bc = math.floor(budget), math.ceil(budget)
+    max_n = max(n_lines)
+    cut = sum(1 for p in range(len(evs)) if pre[p] + max_n <= bf)
+    bits = [0] * n_tot
+    for p in range(cut):
+        bits[evs[p][1]] = evs[p][2] + 2
+    spent = pre[cut]
+    alive = {i for i in range(n_tot) if n_lines[i] + spent <= bf}
+    e = cut
+    while e < len(evs) and spent < bc and alive:
+        _, i, k = evs[e]
+        e += 1
+        if i not in alive:
+            continue
+        spent += 2 * n_lines[i] if k == 0 else n_lines[i]       # (a live band always fits)
+        bits[i] = k + 2
+        alive = {j for j in alive if n_lines[j] + spent <= bf}
+    return np.array(bits), int(budget - spent)
+
+
+def test_bitalloc_event_list_model_equals_greedy_loop():
+    # what chain_prep_kernel / chain_phase_b_kernel implement on the device, against the oracle's restatement of
+    # bitalloc.py:106-155: ties, cross-level ties (multiples of 6), equal SMRs, budgets <= 0, huge budgets (the 16-bit
+    # cap), every maxMantBits, the band tables of all block shapes
+    from oracle.bitalloc import BitAlloc
+    rng = np.random.default_rng(1)
+    nl25 = np.array([4, 5, 4, 4, 5, 5, 6, 6, 7, 8, 9, 10, 12, 14, 16, 19, 24, 30, 38, 47, 56, 76, 107, 149, 363])
+    nl9 = np.array([2, 1, 3, 3, 5, 9, 18, 42, 45])
+    for trial in range(700):
+        kind = trial % 6
+        nl = (nl25, np.concatenate([nl25, nl25]), nl9, np.concatenate([nl9, nl9]))[kind] if kind < 4 \
+            else rng.integers(1, 50, size=rng.integers(1, 30))
+        smr = rng.normal(0, 20, len(nl))
+        if trial % 7 == 0:
+            smr = np.round(smr)
+        if trial % 11 == 0:
+            smr[:] = smr[0]
+        if trial % 13 == 0:
+            smr = np.round(smr / 6) * 6 + 0.0
+        budget = float(rng.choice([5414.28, 2722.64, 561.16, 288.08, 5.0, -3.2, 100000.5, rng.uniform(0, 9000),
+                                   float(rng.integers(0, 6000))]))
+        max_m = int(rng.choice([16, 16, 16, 8, 4, 2]))
+        b0, l0 = BitAlloc(budget, max_m, len(nl), nl, smr.copy())
+        b1, l1 = _alloc_by_event_list(budget, max_m, [int(v) for v in nl], smr)
+        assert np.array_equal(np.asarray(b0).astype(int), b1) and int(l0) == l1, (trial, budget, max_m)
