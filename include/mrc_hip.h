@@ -195,6 +195,10 @@ int mrc_pcm_to_float(mrc_handle* h, int64_t n, const int16_t* pcm, double* out);
  * mrcaudiocodec_amd/transient.py. */
 int mrc_transient_peaks(mrc_handle* h, int64_t n_hops, int n_channels, int n_sections, const double* sos,
                         const double* streams, double* peaks);
+/* ... with the streams given as MRC_SAMPLES_F64 (double*) or MRC_SAMPLES_PCM16 (int16_t*: the WAV's own codes, converted
+ * on load as pcmfile.py:91-100 does) */
+int mrc_transient_peaks_ex(mrc_handle* h, int64_t n_hops, int n_channels, int n_sections, const double* sos,
+                           const void* streams, int sample_format, double* peaks);
 /* The same on streams that are already in DEVICE memory, as float64 signed fractions or as the file's int16 PCM codes
  * (converted on load, pcmfile.py:91-100): channel c starts at streams + c * channel_stride samples; peaks (device)
  * [n_hops][n_channels][nMDCTLines/nSamplesShort + 1]; sos is a HOST pointer.  Enqueued on `stream`. */

@@ -76,6 +76,7 @@ def _load():
         "mrc_scale_factor": (C.c_int, [H, C.c_int64, C.c_int, _f64p, _i32p, _i32p]),
         "mrc_mantissa": (C.c_int, [H, C.c_int64, C.c_int, _f64p, _i32p, _i32p, _i32p]),
         "mrc_transient_peaks": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, _f64p, _f64p, _f64p]),
+        "mrc_transient_peaks_ex": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, _f64p, C.c_void_p, C.c_int, _f64p]),
         "mrc_dev_transient_peaks": (C.c_int, [H, C.c_int64, C.c_int, C.c_int, _f64p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p,
                                               C.c_void_p]),
         "mrc_stereo_masking_factor": (C.c_int, [H, C.c_int64, _f64p, _f64p, _f64p, _f64p, _f64p]),
@@ -623,16 +624,19 @@ class Handle:
         self._check(lib.mrc_dev_pcm16(self._h, n, x, out, stream))
 
     def transient_peaks(self, streams, sos):
-        """streams [nCh][(nHops+1)*hop] -> peaks [nHops][nCh][hop/nShort + 1] (sub-block peaks, then the hop's peak)."""
-        x = _f64(np.atleast_2d(streams))
+        """streams [nCh][(nHops+1)*hop], float64 signed fractions or the file's int16 PCM codes -> peaks
+        [nHops][nCh][hop/nShort + 1] (sub-block peaks, then the hop's peak)."""
+        x = np.atleast_2d(streams)
+        fmt = 1 if x.dtype == np.int16 else 0
+        x = np.ascontiguousarray(x, dtype=np.int16 if fmt else np.float64)
         sos = _f64(sos)
         hop, n_short = self.cfg.n_mdct_lines, self.cfg.n_short
         n_hops = x.shape[1] // hop - 1
         if x.shape[1] != (n_hops + 1) * hop or sos.ndim != 2 or sos.shape[1] != 6:
             raise ValueError("streams must be [nCh][(nHops+1)*hop], sos [nSections][6]")
         out = np.empty((max(n_hops, 0), x.shape[0], hop // n_short + 1), np.float64)
-        self._check(lib.mrc_transient_peaks(self._h, n_hops, x.shape[0], sos.shape[0], _p(sos, _f64p), _p(x, _f64p),
-                                            _p(out, _f64p)))
+        self._check(lib.mrc_transient_peaks_ex(self._h, n_hops, x.shape[0], sos.shape[0], _p(sos, _f64p),
+                                               x.ctypes.data_as(C.c_void_p), fmt, _p(out, _f64p)))
         return out
 
     def dev_transient_peaks(self, n_hops, n_channels, sos, streams_ptr, sample_format, channel_stride, peaks_ptr, stream=None):

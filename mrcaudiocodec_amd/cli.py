@@ -21,9 +21,9 @@ import numpy as np
 from . import Handle, pacfile, transient
 
 
-def read_wav(path, hop=1024, want_pcm=False):
-    """-> (sample_rate, n_channels, num_samples, float64 [nCh][nHops*hop]), last hop zero padded; want_pcm: the int16
-    codes themselves, padded alike, as a fifth item."""
+def read_wav_pcm(path, hop=1024):
+    """-> (sample_rate, n_channels, num_samples, int16 [nCh][nHops*hop]): the file's own codes, the last hop zero padded.
+    The float map of pcmfile.py:91-100 (x = sign(c) 2|c| / 65535, -32768 -> 0.0) is applied on the device, on load."""
     with open(path, "rb") as fp:
         head = fp.read(12)
         if head[0:4] != b"RIFF" or head[8:12] != b"WAVE":
@@ -50,18 +50,24 @@ def read_wav(path, hop=1024, want_pcm=False):
     n_hops = -(-codes.shape[1] // hop)
     pcm = np.zeros((n_ch, n_hops * hop), np.int16)
     pcm[:, :codes.shape[1]] = codes
+    return rate, n_ch, num_samples, pcm
+
+
+def read_wav(path, hop=1024):
+    """-> (sample_rate, n_channels, num_samples, float64 [nCh][nHops*hop]) as pcmfile.py:91-100 hands the samples on."""
+    rate, n_ch, num_samples, pcm = read_wav_pcm(path, hop)
     c = pcm.astype(np.float64)
     mag = np.abs(c)
-    x = np.where(mag >= 32768, 0.0, np.sign(c) * 2.0 * mag / 65535)    # -32768 -> 0.0 (pcmfile.py:91-100)
-    return (rate, n_ch, num_samples, x, pcm) if want_pcm else (rate, n_ch, num_samples, x)
+    return rate, n_ch, num_samples, np.where(mag >= 32768, 0.0, np.sign(c) * 2.0 * mag / 65535)
 
 
 def encode_wav(in_path, out_path=None, use_huffman=True, device_id=0, handle=None, exact_spread=False):
     """exact_spread: evaluate the masker spreading operation by operation like psychoac.py:68-78 (MRC_OPT_EXACT_SPREAD,
     ~30x slower kernel).  Both modes give the reference driver's bytes on every fixture and sweep; neither is
     bit-identical by construction (README.md, "Parity").
-    The whole file is encoded by ONE library call (mrc_encode_chained_stream_pcm16_pac): int16 codes in, `.pac` bytes out."""
-    rate, n_ch, num_samples, hops, pcm = read_wav(in_path, want_pcm=True)
+    The file's int16 codes go to the device as they are: the transient detector (mrc_transient_peaks_ex) and the whole
+    encode loop (ONE call, mrc_encode_chained_stream_pcm16_pac) read them there; 2 bytes per sample on the host."""
+    rate, n_ch, num_samples, pcm = read_wav_pcm(in_path)
     if n_ch != 2:
         raise ValueError("stereo input only (the reference's JointEncode indexes data[0], data[1])")
     h = handle if handle is not None else Handle(sample_rate=rate, device_id=device_id)
@@ -70,12 +76,11 @@ def encode_wav(in_path, out_path=None, use_huffman=True, device_id=0, handle=Non
         h.set_option(1, 1)
     try:
         L = h.cfg.n_mdct_lines
-        stream = np.concatenate([np.zeros((2, L)), hops], axis=1)
-        shapes = transient.block_shapes(h, stream)
-        if not shapes:
+        codes = np.concatenate([np.zeros((2, L), np.int16), pcm], axis=1)      # the zero prior hop (pacfileThem.py:615-618)
+        shapes = transient.block_shape_array(h, codes)
+        if not len(shapes):
             raise ValueError("file too short: fewer than two hops")
-        codes = np.concatenate([np.zeros((2, L), np.int16), pcm], axis=1)
-        if shapes[-1][2] != L:
+        if shapes[-1, 2] != L:
             raise ValueError("the stream must end with a long block (the reference's Close() assumes it)")
         r = h.encode_chained_pac(codes[0][None], codes[1][None], [shapes], use_huffman=use_huffman, with_flush=True,
                                  num_samples=[num_samples])

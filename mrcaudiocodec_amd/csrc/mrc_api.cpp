@@ -1107,25 +1107,32 @@ int mrc_huffman_gain(mrc_handle* h, int64_t n, int a, int b, int n_streams, cons
     return MRC_OK;
 }
 
-int mrc_transient_peaks(mrc_handle* h, int64_t n_hops, int n_channels, int n_sections, const double* sos,
-                        const double* streams, double* peaks) {
-    if (!h || !sos || !streams || !peaks || n_hops < 0 || n_channels < 1 || n_sections < 1 || n_sections > 16)
+int mrc_transient_peaks_ex(mrc_handle* h, int64_t n_hops, int n_channels, int n_sections, const double* sos,
+                           const void* streams, int sample_format, double* peaks) {
+    if (!h || !sos || !streams || !peaks || n_hops < 0 || n_channels < 1 || n_sections < 1 || n_sections > 16 ||
+        (sample_format != MRC_SAMPLES_F64 && sample_format != MRC_SAMPLES_PCM16))
         return fail(h, MRC_ERR_INVALID, "mrc_transient_peaks: bad argument (1 <= n_sections <= 16)");
     if (n_hops == 0) return MRC_OK;
     const int hop = h->cfg.n_mdct_lines, nShort = h->cfg.n_short;
     if (hop % nShort != 0) return fail(h, MRC_ERR_INVALID, "mrc_transient_peaks: n_mdct_lines must be a multiple of n_short");
     const int64_t chStride = (n_hops + 1) * (int64_t)hop;
+    const size_t smp = sample_format == MRC_SAMPLES_PCM16 ? sizeof(int16_t) : sizeof(double);
     MRC_HIP(h, hipSetDevice(h->device));
     Staged s{h, h->stream};
-    MRC_TRY(s.up(h->inL, streams, (size_t)n_channels * chStride * sizeof(double)));
+    MRC_TRY(s.up(h->inL, streams, (size_t)n_channels * chStride * smp));
     MRC_TRY(s.up(h->inAux3, sos, (size_t)n_sections * 6 * sizeof(double)));
     const size_t outBytes = (size_t)n_hops * n_channels * (hop / nShort + 1) * sizeof(double);
     MRC_HIP(h, h->outG.reserve(outBytes));
     MRC_HIP(h, launch_transient_peaks(n_hops, n_channels, hop, nShort, n_sections, h->inAux3.as<double>(),
-                                      h->inL.p, kSampleF64, chStride, h->outG.as<double>(), h->stream));
+                                      h->inL.p, sample_format, chStride, h->outG.as<double>(), h->stream));
     MRC_TRY(s.down(peaks, h->outG, outBytes));
     MRC_HIP(h, hipStreamSynchronize(h->stream));
     return MRC_OK;
+}
+
+int mrc_transient_peaks(mrc_handle* h, int64_t n_hops, int n_channels, int n_sections, const double* sos,
+                        const double* streams, double* peaks) {
+    return mrc_transient_peaks_ex(h, n_hops, n_channels, n_sections, sos, streams, MRC_SAMPLES_F64, peaks);
 }
 
 int mrc_dev_transient_peaks(mrc_handle* h, int64_t n_hops, int n_channels, int n_sections, const double* sos,

@@ -47,6 +47,13 @@ def block_shapes(handle, stream, sos=None, T=THRESHOLDS):
     return shapes_from_flags(transient_positions(handle.transient_peaks(stream, sos), T), hop, n_short)
 
 
+def block_shape_array(handle, stream, sos=None, T=THRESHOLDS):
+    """block_shapes as ONE int64 array [nBlocks][3] = (offset, a, b); `stream` may hold the file's int16 PCM codes."""
+    hop, n_short = handle.cfg.n_mdct_lines, handle.cfg.n_short
+    sos = design_sos(handle.cfg.sample_rate) if sos is None else sos
+    return shape_array_from_flags(transient_positions(handle.transient_peaks(stream, sos), T), hop, n_short)
+
+
 def shapes_from_flags(flags, hop, n_short):
     """pacfileThem.py:1182-1214 given the per-hop transient positions (bool [nHops][nSub]) -> list of (offset, a, b)."""
     return [tuple(r) for r in shape_array_from_flags(flags, hop, n_short).tolist()]

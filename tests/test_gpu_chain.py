@@ -95,7 +95,8 @@ def test_many_streams_with_different_schedules(h):
         np.zeros((2, n)),                                              # digital silence: the reservoir only grows
         np.stack([g, 0.2 * tone]),
     ])
-    shapes = [sh_sw, sh_long, sh_long[:6], sh_long[:4], sh_sw]
+    streams = np.concatenate([streams, np.stack([0.4 * tone, g])[None]])     # ... and a stream of ONE block (+ Close())
+    shapes = [sh_sw, sh_long, sh_long[:6], sh_long[:4], sh_sw, sh_long[:1]]
     got = ppac.encode_stereo_streams(h, streams, shapes)
     for s in range(len(shapes)):
         assert got[s] == opac.encode_stereo_stream(streams[s], shapes[s], huffman=True), s

@@ -100,3 +100,20 @@ def test_cli_encode_wav_bytes_equal_oracle(tmp_path):
     want = opac.encode_wav(str(tmp_path / "b.wav"))
     assert got == want and (tmp_path / "b.pac").read_bytes() == want
     assert cli.encode_wav(str(tmp_path / "b.wav"), use_huffman=False) == opac.encode_wav(str(tmp_path / "b.wav"), huffman=False)
+
+
+@pytest.mark.gpu
+def test_detector_on_int16_codes_equals_detector_on_floats():
+    # mrc_transient_peaks_ex: the WAV's int16 codes are converted on load exactly as pcmfile.py:91-100 does (-32768 -> 0.0)
+    from mrcaudiocodec_amd import Handle, synth, transient as ptr
+    h = Handle(device_id=0)
+    try:
+        pcm = _test_pcm(6 * 1024).astype(np.int16)
+        codes = np.concatenate([np.zeros((2, 1024), np.int16), pcm], axis=1)
+        sos = ptr.design_sos(48000)
+        a = h.transient_peaks(codes, sos)
+        b = h.transient_peaks(synth.pcm_to_float(codes), sos)
+        assert np.array_equal(a, b)
+        assert np.array_equal(ptr.block_shape_array(h, codes, sos), np.asarray(ptr.block_shapes(h, synth.pcm_to_float(codes), sos)))
+    finally:
+        h.close()
