@@ -124,6 +124,8 @@ __device__ __forceinline__ double exp2_tab64(double sT, double u, const double* 
     p = fma(p, g, 0x1.62e42fefa39efp-7);
 #endif
     p = fma(p, g, 1.0);
+    // (the table as two arrays of 32-bit halves -- entry j of either in bank j, conflict-free for any index pattern -- was
+    // measured in round 3: 4.60 against 4.54 ms; like the 32-entry table of round 2 it removes conflicts the waves do not wait for)
     return ldexp(p * tab[n & (kExpTab - 1)], n >> kExpTabShift);
 }
 
