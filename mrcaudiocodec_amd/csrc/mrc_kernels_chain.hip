@@ -260,8 +260,6 @@ template <int NT> struct ChainDims {
     static constexpr int kEvPerThread = (kMaxEvents + NT) / NT;               // the events / prefix sums a thread stages
     static constexpr int kUnitsPerThread = (kMaxLinesPerItem / 4 + NT - 1) / NT;   // units of four lines per thread
 };
-constexpr int kEvPerLane = kMaxEvents / kWave;                                // 15
-constexpr int kMaxGrants = 15;                                                // maxMantBits - 1 <= 15
 // What a thread holds of the coming items.  Stage 1 (one item ahead): the event list, the raw band peak, the raw lines of its
 // units with the signal each comes from.  Stage 2 (two items ahead): the M/S switch of its band and an overall scale -- the
 // lines of an item can only be requested once its M/S switch says which signal each band is coded from (ms_stereo.py:70-81,
@@ -441,8 +439,9 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
     __shared__ unsigned sInfo[kWave];                    // per (stream, band): bits | scale factor << 8
     __shared__ unsigned sEsc[kWave];                     // per (stream, band): bits + escape code length of each table, 8 bits each
     __shared__ unsigned sLut[kLutSize + 1];              // per value: the four code lengths, 8 bits each (0: not in the table)
-    __shared__ unsigned sRed[kChainThreads / kWave][4];
     __shared__ int sCtl[4];                              // remaining bits, raw bits of stream 0 / 1, reservoir
+    __shared__ int sCut;                                 // events that are certain grants (counted by all waves)
+    __shared__ unsigned sAcc[4];                         // Huffman prices of the block, summed over the waves (LDS atomics)
     __shared__ int sItems[256];                          // ring of item ids (see below)
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const int64_t strmId = blockIdx.x;
@@ -454,7 +453,9 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
     }
     unsigned escLen4 = 0;                                // the escape code's length in each table
     for (int t = 0; t < 4; ++t) escLen4 |= (unsigned)kChainCodeLen[t][kChainEscape[t]] << (8 * t);
-    if (tid == 0) sCtl[3] = reservoir[strmId];
+    if (tid == 0) { sCtl[3] = reservoir[strmId]; sCut = 0; }
+    if (tid < 4) sAcc[tid] = 0u;
+    if (tid < kWave) sBits[tid] = 0;
     const long long i0 = itemStart[strmId], i1 = itemStart[strmId + 1];
     ItemRegs<NT> R;
     SwitchRegs W;                                        // the NEXT item's switch and scales
@@ -514,7 +515,7 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
     for (long long it = i0; it < i1; ++it) {
         const int item = itemCur;
         const int64_t idx = item & 0x0fffffff;
-        const int nb = G.nb, nTot = G.nTot, M = G.M, K = G.K, nEv = G.nEv, nstream = G.nstream;
+        const int nb = G.nb, nTot = G.nTot, M = G.M, nEv = G.nEv, nstream = G.nstream;
         MRC_CP(0);
         // ---- this item's event list and peaks: registers -> LDS (its lines stay in registers); the next item's switch
         //      and scales: registers -> the other half of the signal tables
@@ -526,6 +527,31 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
         }
         if (tid < kWave) { sPeak[tid] = R.peak; sSig[par ^ 1][tid] = signal_of(Ln, tid, W.sig); }
         if (tid < 4) sOsc[par ^ 1][tid] = W.osc;
+        // ---- bit allocation (bitalloc.py:106-155), its HEAD by all waves, straight from the registers that hold the event
+        //      list: the budget of codecThem.py:299-308 / 381-396 from the reservoir the previous item left; the events whose
+        //      cost prefix leaves at least max(nLines) bits are certain grants -- counted (the cut), and every band's bits
+        //      raised to what its last such grant gives.  (nLines <= left <=> nLines + spent <= Bf; left > 0 <=> spent < Bc)
+        double budget;
+        {
+            const double r = (double)sCtl[3];
+            if (G.joint) { budget = G.budgetJointPre + r; budget -= G.blkswA; budget -= G.blkswB; }
+            else budget = G.budgetMono + r;
+        }
+        const int Bf = (int)fmin(fmax(floor(budget), -1.0e9), 1.0e9), Bc = (int)fmin(fmax(ceil(budget), -1.0e9), 1.0e9);
+        {
+            const int maxN = G.maxN;
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < kEvPerThread; ++j) {
+                const int p = tid + kChainThreads * j;
+                if (p < nEv && (int)R.pre[j] + maxN <= Bf) {
+                    ++cnt;
+                    atomicMax(&sBits[R.ev[j] & 63u], (int)((R.ev[j] >> 6) & 31u));
+                }
+            }
+            cnt = wave_sum_i(cnt);
+            if (lane == 0 && cnt) atomicAdd(&sCut, cnt);
+        }
         double xr[kUnitsPerThread][4];
         unsigned sigsOf[kUnitsPerThread];
 #pragma unroll
@@ -556,32 +582,10 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
         }
         MRC_CP(3);
         if (wave == 0) {
-            // ---- bit allocation (bitalloc.py:106-155) for the budget of codecThem.py:299-308 / 381-396
-            const double r = (double)sCtl[3];
-            double budget;
-            if (G.joint) { budget = G.budgetJointPre + r; budget -= G.blkswA; budget -= G.blkswB; }
-            else budget = G.budgetMono + r;
-            // nLines <= left  <=>  nLines + spent <= Bf;  left > 0  <=>  spent < Bc  (spent: an integer below 2^16)
-            const int Bf = (int)fmin(fmax(floor(budget), -1.0e9), 1.0e9), Bc = (int)fmin(fmax(ceil(budget), -1.0e9), 1.0e9);
-            // how many events are certain grants: fewer than maxN bits have been spent short of the budget
-            const int maxN = G.maxN;
-            // (all reads unconditional and issued together -- the arrays are padded -- then masked: a guarded read would wait
-            // for its LDS round trip before the next one is issued)
-            int preV[kEvPerLane];
-#pragma unroll
-            for (int j = 0; j < kEvPerLane; ++j) preV[j] = (int)sPre[lane + kWave * j];
-            int cnt = 0;
-#pragma unroll
-            for (int j = 0; j < kEvPerLane; ++j) cnt += ((lane + kWave * j < nEv) & (preV[j] + maxN <= Bf)) ? 1 : 0;
-            const int cut = wave_sum_i(cnt);
+            // ---- the rest of the allocation: the tail behind the cut
+            const int cut = sCut;
             const bool valid = lane < nTot;
-            int posV[kMaxGrants];
-#pragma unroll
-            for (int k = 0; k < kMaxGrants; ++k) posV[k] = (int)sPos[min(k * nTot, kMaxEvents) + lane];
-            int c = 0;
-#pragma unroll
-            for (int k = 0; k < kMaxGrants; ++k) c += ((k < K) & (posV[k] < cut)) ? 1 : 0;
-            int myBits = (valid && c) ? c + 1 : 0;                         // the first grant gives two bits
+            int myBits = valid ? sBits[lane] : 0;
             const int myN = valid ? nCur : 0;
             int spent = (int)sPre[cut];
             MRC_CP(4);
@@ -592,7 +596,6 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
             // it is granted in one go, the live set is brought up to date, and the rest of the batch is looked at again.
             unsigned long long alive = nTot >= 64 ? ~0ull : ((1ull << nTot) - 1ull);
             alive &= ~__ballot(valid && myN + spent > Bf);
-            sBits[lane] = myBits;
             int e = cut;
             bool done = !(spent < Bc) || alive == 0ull;
             while (!done && e < nEv) {
@@ -621,6 +624,8 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
             }
             wave_sync();
             myBits = sBits[lane];
+            sBits[lane] = 0;                                                   // (for the next item's head)
+            if (lane == 0) sCut = 0;
             MRC_CP(5);
 #ifdef MRC_CHAIN_PROFILE
             if (tid == 0) { atomicAdd(&gChainProf[12], (unsigned long long)(e - cut)); atomicAdd(&gChainProf[13], 1ull); }
@@ -695,18 +700,15 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
             // bytes -> 16-bit fields (per table at most 25 bits x 1024 lines): tables 0 | 2 and 1 | 3 of each stream
             const unsigned w0 = (unsigned)wave_sum_i((int)(accA & 0x00ff00ffu)), w1 = (unsigned)wave_sum_i((int)((accA >> 8) & 0x00ff00ffu));
             const unsigned w2 = (unsigned)wave_sum_i((int)(accB & 0x00ff00ffu)), w3 = (unsigned)wave_sum_i((int)((accB >> 8) & 0x00ff00ffu));
-            if (lane == 0) { sRed[wave][0] = w0; sRed[wave][1] = w1; sRed[wave][2] = w2; sRed[wave][3] = w3; }
+            if (lane == 0) { atomicAdd(&sAcc[0], w0); atomicAdd(&sAcc[1], w1); atomicAdd(&sAcc[2], w2); atomicAdd(&sAcc[3], w3); }
         }
         MRC_CP(8);
         __syncthreads();
         MRC_CP(9);
         if (tid == 0) {
-            unsigned w[4] = {0u, 0u, 0u, 0u};
+            unsigned w[4];
 #pragma unroll
-            for (int v = 0; v < kChainThreads / kWave; ++v) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) w[q] += sRed[v][q];
-            }
+            for (int q = 0; q < 4; ++q) { w[q] = sAcc[q]; sAcc[q] = 0u; }
             int res = sCtl[0];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
