@@ -417,13 +417,14 @@ class Handle:
                 np.ascontiguousarray(flat[:, 2], dtype=np.int32))
 
     def encode_chained_pac(self, pcm_left, pcm_right, shapes, use_huffman=True, with_flush=True, num_samples=None,
-                           reservoir_in=None, want_trace=False, device=None, stream=None):
+                           reservoir_in=None, want_trace=False, device=None, stream=None, want_items=False):
         """mrc_encode_chained_stream_pac: stereo streams [nStreams][stride] -- int16 PCM codes or float64 signed fractions,
         each starting with its prior hop -- + the block shapes of every stream -> the `.pac` bytes of every stream (with
         num_samples: complete files, header included), the bit reservoir carried from block to block on the device.
         device = (left_ptr, right_ptr, sample_format, stride, out_ptr, out_cap): everything stays in HBM
         (mrc_dev_encode_chained_pac; `bytes` is then None).
-        -> dict: bytes (uint8), stream_offset [nStreams + 1], item_offset, reservoir_out [nStreams], total, (trace)."""
+        -> dict: bytes (uint8), stream_offset [nStreams + 1], reservoir_out [nStreams], total, (trace), and with want_items
+        item_offset [nItems + 1]: where every block's bytes start (costs a read-back of all chunk positions)."""
         start, off, a, b = self._chain_schedule(shapes)
         n_streams = len(shapes)
         if device is None:
@@ -439,7 +440,7 @@ class Handle:
             raise ValueError("num_samples: one value per stream")
         res_in = _reservoir(reservoir_in, n_streams)
         s_off = np.zeros(n_streams + 1, np.int64)
-        i_off = np.zeros(n_items + 1, np.int64)
+        i_off = np.zeros(n_items + 1, np.int64) if want_items else None
         res_out = np.zeros(n_streams, np.int32)
         trace = np.zeros(n_items, np.int32) if want_trace else None
         total = np.zeros(1, np.int64)

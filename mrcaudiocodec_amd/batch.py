@@ -120,12 +120,12 @@ class StreamEncoder:
         return table, saved, nxt
 
     def encode_chained_pac(self, left, right, shapes, use_huffman=True, with_flush=True, num_samples=None, reservoir_in=None,
-                           out=None):
+                           out=None, want_items=False):
         """The reference's whole encode loop for stereo streams that are RESIDENT in HBM (mrc_dev_encode_chained_pac): left /
         right [nStreams][stride] device tensors (int16 PCM codes or float64), shapes[s] = the (offset, a, b) sequence of
         stream s (lists or int arrays [n][3]).  -> dict: bytes (device uint8 tensor, the used prefix), stream_offset /
-        item_offset / reservoir_out (host arrays), total; `out`: a device uint8 tensor to write into (else allocated at the
-        worst-case size)."""
+        reservoir_out (host arrays), item_offset (with want_items, else None), total; `out`: a device uint8 tensor to write
+        into (else allocated at the worst-case size)."""
         from . import _lib
         if left.dim() == 1:
             left, right = left[None], right[None]
@@ -151,7 +151,8 @@ class StreamEncoder:
         r = self.h.encode_chained_pac(None, None, shapes, use_huffman=use_huffman, with_flush=with_flush,
                                       num_samples=num_samples, reservoir_in=reservoir_in,
                                       device=(left.data_ptr(), right.data_ptr(), 1 if left.dtype == torch.int16 else 0,
-                                              left.shape[1], out.data_ptr(), out.numel()), stream=stream)
+                                              left.shape[1], out.data_ptr(), out.numel()), stream=stream,
+                                      want_items=want_items)
         r["bytes"] = out[:r["total"]]
         return r
 

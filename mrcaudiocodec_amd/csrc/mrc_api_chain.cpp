@@ -86,78 +86,35 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
             return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: shape outside what the chained back end covers "
                                             "(<= 32 bands, 2..16 mantissa bits, lines a multiple of 4)");
     }
-    // ---- the schedule: items (group << 28 | index inside the group) per stream in file order
+    // ---- the schedule, pass 1: validate, sort the blocks into their shape groups (the offsets phase A needs).  The rest of
+    // the schedule (items in file order, chunk maps, headers) is only needed by the serial scan and the packer: it is built
+    // and uploaded in pass 2, AFTER phase A's launches are queued, so the device works while the host prepares it.
     const int64_t nItems = nB + (with_flush ? 2 * n_streams : 0);
     const int64_t nChunks = 2 * nB + (with_flush ? 2 * n_streams : 0);
-    std::vector<int32_t> items((size_t)nItems);
-    std::vector<long long> itemStart((size_t)n_streams + 1), firstChunk((size_t)n_streams), tailOff((size_t)n_streams);
-    std::vector<long long> itemChunk((size_t)nItems + 1);
-    std::vector<int32_t> chunkStream((size_t)nChunks);
+    std::vector<uint8_t> groupOf((size_t)nB);
     std::vector<int64_t> offs[kChainGroups];
-    std::vector<long long> chunkMap[kChainGroups];
-    std::vector<int32_t> resIn((size_t)n_streams, 0);
+    std::vector<long long> tailOff((size_t)n_streams);
     offs[0].reserve((size_t)nB);
-    chunkMap[0].reserve((size_t)2 * nB);
-    if (with_flush) chunkMap[4].reserve((size_t)2 * n_streams);
-    {
-        int64_t it = 0, ch = 0;
-        for (int64_t s = 0; s < n_streams; ++s) {
-            itemStart[(size_t)s] = it;
-            firstChunk[(size_t)s] = ch;
-            const int64_t i0 = block_start[s], i1 = block_start[s + 1];
-            if (i1 <= i0) return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: every stream needs at least one block");
-            for (int64_t i = i0; i < i1; ++i) {
-                const int a = block_a[i], b = block_b[i];
-                int g = -1;
-                for (int q = 0; q < 4; ++q) if (a == shapeA[q] && b == shapeB[q]) { g = q; break; }   // (L == Sh: group 0)
-                if (g < 0) return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: block shape is not one of (L,L), (L,S), (S,S), (S,L)");
-                const int64_t off = block_offset[i];
-                if (off < 0 || off + a + b > stream_stride)
-                    return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: block reaches outside its stream");
-                if (offs[g].size() >= (size_t)1 << 28) return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: too many blocks of one shape");
-                items[(size_t)it] = (int32_t)((unsigned)g << 28 | (unsigned)offs[g].size());
-                offs[g].push_back(s * stream_stride + off);
-                chunkMap[g].push_back(ch); chunkMap[g].push_back(ch + 1);
-                itemChunk[(size_t)it] = ch;
-                chunkStream[(size_t)ch] = chunkStream[(size_t)ch + 1] = (int32_t)s;
-                ch += 2; ++it;
-            }
-            if (with_flush) {
-                if (block_b[i1 - 1] != L)
-                    return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: a stream must end with a long block (the reference's "
-                                                    "Close() assumes it, pacfileThem.py:973-984)");
-                tailOff[(size_t)s] = block_offset[i1 - 1] + block_a[i1 - 1];
-                for (int c = 0; c < 2; ++c) {                      // codec.Encode: channel after channel
-                    items[(size_t)it] = (int32_t)(4u << 28 | (unsigned)(2 * s + c));
-                    chunkMap[4].push_back(ch);
-                    itemChunk[(size_t)it] = ch;
-                    chunkStream[(size_t)ch] = (int32_t)s;
-                    ++ch; ++it;
-                }
-            }
-            if (reservoir_in) resIn[(size_t)s] = reservoir_in[s];
+    for (int64_t s = 0; s < n_streams; ++s) {
+        const int64_t i0 = block_start[s], i1 = block_start[s + 1];
+        if (i1 <= i0) return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: every stream needs at least one block");
+        for (int64_t i = i0; i < i1; ++i) {
+            const int a = block_a[i], b = block_b[i];
+            int g = -1;
+            for (int q = 0; q < 4; ++q) if (a == shapeA[q] && b == shapeB[q]) { g = q; break; }   // (L == Sh: group 0)
+            if (g < 0) return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: block shape is not one of (L,L), (L,S), (S,S), (S,L)");
+            const int64_t off = block_offset[i];
+            if (off < 0 || off + a + b > stream_stride)
+                return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: block reaches outside its stream");
+            if (offs[g].size() >= (size_t)1 << 28) return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: too many blocks of one shape");
+            groupOf[(size_t)(i - b0)] = (uint8_t)g;
+            offs[g].push_back(s * stream_stride + off);
         }
-        itemStart[(size_t)n_streams] = it;
-        itemChunk[(size_t)nItems] = ch;
-    }
-    // ---- file headers (pacfileThem.py:586-613)
-    int hdrLen = 0;
-    std::vector<uint8_t> hdr;
-    if (num_samples) {
-        // one header built by mrc_pac_header; the streams differ only in the sample count (bytes 10..13, little endian, with
-        // the reference's padding rule, pacfileThem.py:595-597: padded when it ALREADY is a multiple of nMDCTLines)
-        uint8_t one[256];
-        int64_t len = 0;
-        if (mrc_pac_header(&cfg, 2, num_samples[0], one, sizeof(one), &len) != MRC_OK || len < 14)
-            return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: mrc_pac_header failed");
-        hdrLen = (int)len;
-        hdr.resize((size_t)n_streams * len);
-        for (int64_t s = 0; s < n_streams; ++s) {
-            uint8_t* dst = hdr.data() + s * len;
-            std::memcpy(dst, one, (size_t)len);
-            uint32_t ns = num_samples[s];
-            if (ns % (uint32_t)cfg.n_mdct_lines == 0) ns += (uint32_t)cfg.n_mdct_lines;
-            for (int q = 0; q < 4; ++q) dst[10 + q] = (uint8_t)(ns >> (8 * q));
+        if (with_flush) {
+            if (block_b[i1 - 1] != L)
+                return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: a stream must end with a long block (the reference's "
+                                                "Close() assumes it, pacfileThem.py:973-984)");
+            tailOff[(size_t)s] = block_offset[i1 - 1] + block_a[i1 - 1];
         }
     }
 
@@ -165,18 +122,16 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
     hipStream_t st = pick_stream(h, stream);
     ChainBufs& C = h->chain;
     for (auto& e : C.evT) if (!e) MRC_HIP(h, hipEventCreate(&e));
-    std::vector<long long> pos((size_t)nChunks + 1);
+    std::vector<long long> pos(item_byte_offset ? (size_t)nChunks + 1 : 0), streamPos((size_t)n_streams);
     std::vector<int32_t> resOut((size_t)n_streams);
+    // (filled in pass 2; declared here: the guard below outlives every host buffer a queued copy may still read)
+    std::vector<int32_t> items, chunkStream, resIn;
+    std::vector<long long> itemStart, firstChunk, itemChunk, chunkMap[kChainGroups];
+    std::vector<uint8_t> hdr;
     long long total = 0;
     int bad = 0;
     SyncGuard guard{st};
     MRC_HIP(h, hipEventRecord(C.evT[0], st));
-    MRC_TRY(upload(h, C.items, items, st));
-    MRC_TRY(upload(h, C.itemStart, itemStart, st));
-    MRC_TRY(upload(h, C.reservoir, resIn, st));
-    MRC_TRY(upload(h, C.chunkStream, chunkStream, st));
-    MRC_TRY(upload(h, C.hdr, hdr, st));
-    if (reservoir_trace) MRC_HIP(h, C.resTrace.reserve((size_t)nItems * sizeof(int32_t)));
     if (with_flush) {
         // the tail offsets ride in the offsets buffer of group 4 (its blocks are laid out explicitly, stride 2 L)
         MRC_TRY(upload(h, C.g[4].offsets, tailOff, st));
@@ -197,7 +152,6 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
         const int nTot = nstream * S.nBands, nEv = (int)chain_events_per_block(S, joint);
         if (m > 0) {
             if (g != 4) MRC_TRY(upload(h, B.offsets, offs[g], st));
-            MRC_TRY(upload(h, B.chunkMap, chunkMap[g], st));
             MRC_HIP(h, B.lines.reserve((size_t)m * nsig * S.halfN * sizeof(double)));
             MRC_HIP(h, B.oscale.reserve((size_t)m * nsig * sizeof(int32_t)));
             MRC_HIP(h, B.smr.reserve((size_t)m * nsig * S.nBands * sizeof(double)));
@@ -234,6 +188,71 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
         D.bitAlloc = B.bitAlloc.as<int32_t>(); D.scaleFactor = B.scaleFactor.as<int32_t>();
         D.mant = B.mant.as<unsigned short>(); D.table = B.table.as<int32_t>();
     }
+    // ---- the schedule, pass 2 (the device is busy with phase A): items (group << 28 | index inside the group) per stream in
+    // file order, the chunk of every item, the stream of every chunk, the chunks of every group
+    items.resize((size_t)nItems);
+    itemStart.resize((size_t)n_streams + 1); firstChunk.resize((size_t)n_streams);
+    itemChunk.resize((size_t)nItems + 1);
+    chunkStream.resize((size_t)nChunks);
+    resIn.assign((size_t)n_streams, 0);
+    for (int g = 0; g < 4; ++g) chunkMap[g].resize(2 * offs[g].size());
+    if (with_flush) chunkMap[4].resize((size_t)2 * n_streams);
+    {
+        int64_t it = 0, ch = 0;
+        size_t idx[kChainGroups] = {};
+        for (int64_t s = 0; s < n_streams; ++s) {
+            itemStart[(size_t)s] = it;
+            firstChunk[(size_t)s] = ch;
+            for (int64_t i = block_start[s]; i < block_start[s + 1]; ++i) {
+                const int g = groupOf[(size_t)(i - b0)];
+                const size_t k = idx[g]++;
+                items[(size_t)it] = (int32_t)((unsigned)g << 28 | (unsigned)k);
+                chunkMap[g][2 * k] = ch; chunkMap[g][2 * k + 1] = ch + 1;
+                itemChunk[(size_t)it] = ch;
+                chunkStream[(size_t)ch] = chunkStream[(size_t)ch + 1] = (int32_t)s;
+                ch += 2; ++it;
+            }
+            if (with_flush)
+                for (int c = 0; c < 2; ++c) {                      // codec.Encode: channel after channel
+                    items[(size_t)it] = (int32_t)(4u << 28 | (unsigned)(2 * s + c));
+                    chunkMap[4][(size_t)(2 * s + c)] = ch;
+                    itemChunk[(size_t)it] = ch;
+                    chunkStream[(size_t)ch] = (int32_t)s;
+                    ++ch; ++it;
+                }
+            if (reservoir_in) resIn[(size_t)s] = reservoir_in[s];
+        }
+        itemStart[(size_t)n_streams] = it;
+        itemChunk[(size_t)nItems] = ch;
+    }
+    // ---- file headers (pacfileThem.py:586-613)
+    int hdrLen = 0;
+    if (num_samples) {
+        // one header built by mrc_pac_header; the streams differ only in the sample count (bytes 10..13, little endian, with
+        // the reference's padding rule, pacfileThem.py:595-597: padded when it ALREADY is a multiple of nMDCTLines)
+        uint8_t one[256];
+        int64_t len = 0;
+        if (mrc_pac_header(&cfg, 2, num_samples[0], one, sizeof(one), &len) != MRC_OK || len < 14)
+            return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: mrc_pac_header failed");
+        hdrLen = (int)len;
+        hdr.resize((size_t)n_streams * len);
+        for (int64_t s = 0; s < n_streams; ++s) {
+            uint8_t* dst = hdr.data() + s * len;
+            std::memcpy(dst, one, (size_t)len);
+            uint32_t ns = num_samples[s];
+            if (ns % (uint32_t)cfg.n_mdct_lines == 0) ns += (uint32_t)cfg.n_mdct_lines;
+            for (int q = 0; q < 4; ++q) dst[10 + q] = (uint8_t)(ns >> (8 * q));
+        }
+    }
+    MRC_TRY(upload(h, C.items, items, st));
+    MRC_TRY(upload(h, C.itemStart, itemStart, st));
+    MRC_TRY(upload(h, C.reservoir, resIn, st));
+    MRC_TRY(upload(h, C.chunkStream, chunkStream, st));
+    MRC_TRY(upload(h, C.hdr, hdr, st));
+    MRC_TRY(upload(h, C.firstChunk, firstChunk, st));
+    for (int g = 0; g < nGroups; ++g)
+        if (count[g] > 0) MRC_TRY(upload(h, C.g[g].chunkMap, chunkMap[g], st));
+    if (reservoir_trace) MRC_HIP(h, C.resTrace.reserve((size_t)nItems * sizeof(int32_t)));
     MRC_HIP(h, C.groupDesc.reserve(sizeof(desc)));
     MRC_HIP(h, hipMemcpyAsync(C.groupDesc.p, desc, sizeof(desc), hipMemcpyHostToDevice, st));
     MRC_HIP(h, hipEventRecord(C.evT[1], st));
@@ -271,14 +290,16 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
                                      B.table.as<int>(), W, B.chunkMap.as<long long>(), out, (long long)out_cap, bound,
                                      all_bands_non_empty(*hs[g]), st));
     }
-    if (num_samples) {
-        MRC_TRY(upload(h, C.firstChunk, firstChunk, st));
-        MRC_HIP(h, launch_chain_headers(n_streams, hdrLen, C.hdr.as<unsigned char>(), C.firstChunk.as<long long>(), W.pos, out,
-                                        (long long)out_cap, st));
-    }
+    // the file headers (num_samples given), and the start of every stream's bytes
+    MRC_HIP(h, C.streamPos.reserve((size_t)n_streams * sizeof(long long)));
+    MRC_HIP(h, launch_chain_headers(n_streams, hdrLen, C.hdr.as<unsigned char>(), C.firstChunk.as<long long>(), W.pos, out,
+                                    (long long)out_cap, C.streamPos.as<long long>(), st));
     MRC_HIP(h, hipEventRecord(C.evT[3], st));
-    // ---- results: chunk positions, total, error flag, reservoirs
-    MRC_HIP(h, hipMemcpyAsync(pos.data(), W.pos, pos.size() * sizeof(long long), hipMemcpyDeviceToHost, st));
+    // ---- results: stream starts (the position of every chunk only if the caller asked for them), total, error flag,
+    // reservoirs
+    if (item_byte_offset)
+        MRC_HIP(h, hipMemcpyAsync(pos.data(), W.pos, pos.size() * sizeof(long long), hipMemcpyDeviceToHost, st));
+    MRC_HIP(h, hipMemcpyAsync(streamPos.data(), C.streamPos.p, streamPos.size() * sizeof(long long), hipMemcpyDeviceToHost, st));
     MRC_HIP(h, hipMemcpyAsync(&total, W.total, sizeof(total), hipMemcpyDeviceToHost, st));
     MRC_HIP(h, hipMemcpyAsync(&bad, W.errorFlag, sizeof(bad), hipMemcpyDeviceToHost, st));
     MRC_HIP(h, hipMemcpyAsync(resOut.data(), C.reservoir.p, resOut.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -296,7 +317,7 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
         h->chainMs[3] = ms;
     }
     *total_bytes = total;
-    for (int64_t s = 0; s < n_streams; ++s) stream_byte_offset[s] = pos[(size_t)firstChunk[(size_t)s]] - hdrLen;
+    for (int64_t s = 0; s < n_streams; ++s) stream_byte_offset[s] = streamPos[(size_t)s];
     stream_byte_offset[n_streams] = total;
     if (item_byte_offset) {
         for (int64_t i = 0; i < nItems; ++i) item_byte_offset[i] = pos[(size_t)itemChunk[(size_t)i]];

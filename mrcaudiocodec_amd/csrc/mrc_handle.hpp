@@ -69,12 +69,13 @@ struct ChainGroupBufs {
 };
 struct ChainBufs {
     ChainGroupBufs g[kChainGroups];
-    DevBuf pcmL, pcmR, flushPcm, items, itemStart, reservoir, groupDesc, packWs, out, hdr, chunkStream, resTrace, firstChunk;
+    DevBuf pcmL, pcmR, flushPcm, items, itemStart, reservoir, groupDesc, packWs, out, hdr, chunkStream, resTrace, firstChunk,
+        streamPos;
     hipEvent_t evT[4] = {};          // phase timing: start | phase A done | phase B done | packed
     void release() {
         for (auto& x : g) x.release();
         for (DevBuf* b : {&pcmL, &pcmR, &flushPcm, &items, &itemStart, &reservoir, &groupDesc, &packWs, &out, &hdr,
-                          &chunkStream, &resTrace, &firstChunk})
+                          &chunkStream, &resTrace, &firstChunk, &streamPos})
             b->release();
         for (auto& e : evT) { if (e) (void)hipEventDestroy(e); e = nullptr; }
     }

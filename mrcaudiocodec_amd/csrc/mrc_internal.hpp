@@ -172,7 +172,8 @@ hipError_t launch_chain_phase_b(int64_t nStreams, const ChainGroupDev* groups, c
 hipError_t launch_chain_flush_gather(int64_t nStreams, int L, const void* pcmL, const void* pcmR, int fmt, int64_t stride,
                                      const long long* tailOffset, void* out, hipStream_t st);
 hipError_t launch_chain_headers(int64_t nStreams, int hdrLen, const unsigned char* hdr, const long long* firstChunk,
-                                const long long* pos, unsigned char* out, long long outCap, hipStream_t st);
+                                const long long* pos, unsigned char* out, long long outCap, long long* streamPos,
+                                hipStream_t st);
 // mrc_kernels_huff.hip
 hipError_t launch_huffman_gain(const DevShape& S, int64_t nFrames, int nStreams, const int* bitAlloc,
                                const int* mantissa, const int* reservoirOut, int* huffTable, int* bitsSaved,

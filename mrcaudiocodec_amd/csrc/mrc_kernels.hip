@@ -132,10 +132,18 @@ __global__ void unscale_kernel(int halfN, int64_t total, const double* __restric
 // same operation order) and the peak |y| of each short sub-block plus the peak of the whole hop are kept.
 // One thread per (hop, channel): the recurrence is serial in time, hops are independent.
 constexpr int kMaxSections = 16;
-template <class SampleT>
-__global__ void transient_peaks_kernel(int64_t nHops, int nCh, int hop, int nShort, int nSec,
-                                       const double* __restrict__ sos, const SampleT* __restrict__ streams,
-                                       int64_t chStride, double* __restrict__ peaks) {
+// NSEC > 0: the section count is a compile-time constant and the 5 x NSEC coefficients live in VECTOR registers (loaded
+// through an address the compiler cannot prove uniform).  Left to itself the compiler keeps them behind scalar loads INSIDE
+// the sample loop -- ten dependent scalar-memory round trips per sample for the reference's 20th-order filter, which is what
+// the kernel's time used to be (0.87 ms per 131 072 hops); 100 scalar registers would not fit either.
+// VEC: every hop starts on a 16-byte boundary: the samples come eight (int16) / two (double) per load, and the next group is
+// requested before the current one is filtered.
+// NSEC == 0: any section count up to kMaxSections, coefficients as the compiler pleases.
+template <class SampleT, int NSEC, bool VEC>
+__global__ __launch_bounds__(kWave) void transient_peaks_kernel(int64_t nHops, int nCh, int hop, int nShort, int nSecArg,
+                                                                 const double* __restrict__ sos,
+                                                                 const SampleT* __restrict__ streams, int64_t chStride,
+                                                                 double* __restrict__ peaks) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nHops * nCh) return;
     const int64_t h = t / nCh;
@@ -143,31 +151,73 @@ __global__ void transient_peaks_kernel(int64_t nHops, int nCh, int hop, int nSho
     const SampleT* x = streams + ch * chStride + (h + 1) * hop;         // the stream starts with the prior hop
     const int nSub = hop / nShort;
     double* out = peaks + t * (nSub + 1);
-    double z0[kMaxSections], z1[kMaxSections];
+    constexpr int kSec = NSEC ? NSEC : kMaxSections;
+    const int nSec = NSEC ? NSEC : nSecArg;
+    double z0[kSec], z1[kSec];
+    double b0[kSec], b1[kSec], b2[kSec], a1[kSec], a2[kSec];
+    int lane0 = 0;
+    if (NSEC) asm volatile("" : "+v"(lane0));                        // an opaque zero: per-lane (vector) loads below
 #pragma unroll
-    for (int s = 0; s < kMaxSections; ++s) { z0[s] = 0.0; z1[s] = 0.0; }
+    for (int s = 0; s < kSec; ++s) {
+        z0[s] = 0.0; z1[s] = 0.0;
+        if (NSEC) {
+            b0[s] = sos[6 * s + lane0]; b1[s] = sos[6 * s + 1 + lane0]; b2[s] = sos[6 * s + 2 + lane0];
+            a1[s] = sos[6 * s + 4 + lane0]; a2[s] = sos[6 * s + 5 + lane0];
+        }
+    }
+    // one sample through the cascade (scipy.signal.sosfilt's recurrence, same operation order)
+    auto cascade = [&](double cur) -> double {
+#pragma unroll
+        for (int s = 0; s < kSec; ++s) {
+            if (s < nSec) {
+                const double c0 = NSEC ? b0[s] : sos[6 * s], c1 = NSEC ? b1[s] : sos[6 * s + 1];
+                const double c2 = NSEC ? b2[s] : sos[6 * s + 2];
+                const double d1 = NSEC ? a1[s] : sos[6 * s + 4], d2 = NSEC ? a2[s] : sos[6 * s + 5];
+                const double y = c0 * cur + z0[s];
+                z0[s] = (c1 * cur - d1 * y) + z1[s];
+                z1[s] = c2 * cur - d2 * y;
+                cur = y;
+            }
+        }
+        return cur;
+    };
     double all = 0.0;
-    for (int sb = 0; sb < nSub; ++sb) {
-        double pk = 0.0;
-        // (unrolling this loop by four, so that the cascades of neighbouring samples overlap, was measured: 0.99 instead of
-        // 0.87 ms per 131 072 hops -- the section loop below already fills the pipe)
-        for (int n = 0; n < nShort; ++n) {
-            double cur = sample_of(x, sb * nShort + n);
+    if (VEC) {
+        constexpr int kGroup = 16 / sizeof(SampleT);                   // samples per 16-byte load
+        typedef int int4n __attribute__((ext_vector_type(4)));
+        const int4n* xv = reinterpret_cast<const int4n*>(x);
+        const int groupsPerSub = nShort / kGroup, nGroups = hop / kGroup;
+        int4n nxt = xv[0];
+        int g = 0;
+        for (int sb = 0; sb < nSub; ++sb) {
+            double pk = 0.0;
+            for (int gi = 0; gi < groupsPerSub; ++gi, ++g) {
+                const int4n cur = nxt;
+                nxt = xv[min(g + 1, nGroups - 1)];
 #pragma unroll
-            for (int s = 0; s < kMaxSections; ++s) {
-                if (s < nSec) {
-                    const double b0 = sos[6 * s], b1 = sos[6 * s + 1], b2 = sos[6 * s + 2];
-                    const double a1 = sos[6 * s + 4], a2 = sos[6 * s + 5];
-                    const double y = b0 * cur + z0[s];
-                    z0[s] = (b1 * cur - a1 * y) + z1[s];
-                    z1[s] = b2 * cur - a2 * y;
-                    cur = y;
+                for (int j = 0; j < kGroup; ++j) {
+                    double v;
+                    if (sizeof(SampleT) == 2) {
+                        const int w = cur[j >> 1];
+                        v = pcm16_to_frac((j & 1) ? (w >> 16) : (int)(short)(w & 0xffff));
+                    } else {
+                        v = __hiloint2double(cur[2 * j + 1], cur[2 * j]);
+                    }
+                    pk = fmax(pk, fabs(cascade(v)));
                 }
             }
-            pk = fmax(pk, fabs(cur));
+            out[sb] = pk;
+            all = fmax(all, pk);
         }
-        out[sb] = pk;
-        all = fmax(all, pk);
+    } else {
+        for (int sb = 0; sb < nSub; ++sb) {
+            double pk = 0.0;
+            // (unrolling this loop by four, so that the cascades of neighbouring samples overlap, was measured: slower --
+            // the section loop already fills the pipe)
+            for (int n = 0; n < nShort; ++n) pk = fmax(pk, fabs(cascade(sample_of(x, sb * nShort + n))));
+            out[sb] = pk;
+            all = fmax(all, pk);
+        }
     }
     out[nSub] = all;
 }
@@ -333,12 +383,17 @@ hipError_t launch_transient_peaks(int64_t nHops, int nCh, int hop, int nShort, i
                                   const void* streams, int fmt, int64_t chStride, double* peaks, hipStream_t st) {
     const int64_t n = nHops * nCh;
     if (n <= 0) return hipSuccess;
-    if (fmt == kSampleI16)
-        hipLaunchKernelGGL(transient_peaks_kernel<short>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, nHops, nCh, hop,
-                           nShort, nSec, sos, (const short*)streams, chStride, peaks);
-    else
-        hipLaunchKernelGGL(transient_peaks_kernel<double>, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, nHops, nCh, hop,
-                           nShort, nSec, sos, (const double*)streams, chStride, peaks);
+    const size_t sz = fmt == kSampleI16 ? sizeof(short) : sizeof(double);
+    const bool vec = !(reinterpret_cast<uintptr_t>(streams) & 15) && !((chStride * sz) & 15) && !((hop * sz) & 15) &&
+                     !((nShort * sz) & 15) && nShort > 0 && hop % nShort == 0;
+    const dim3 grid((unsigned)((n + kWave - 1) / kWave)), block(kWave);
+#define MRC_TP_LAUNCH(TY, NS, VC)                                                                                     \
+    hipLaunchKernelGGL((transient_peaks_kernel<TY, NS, VC>), grid, block, 0, st, nHops, nCh, hop, nShort, nSec, sos,   \
+                       (const TY*)streams, chStride, peaks)
+    // the reference's filter (cheby2 of order 20: ten sections) on aligned hops takes the specialised form
+    if (fmt == kSampleI16) { if (nSec == 10 && vec) MRC_TP_LAUNCH(short, 10, true); else MRC_TP_LAUNCH(short, 0, false); }
+    else { if (nSec == 10 && vec) MRC_TP_LAUNCH(double, 10, true); else MRC_TP_LAUNCH(double, 0, false); }
+#undef MRC_TP_LAUNCH
     return hipGetLastError();
 }
 

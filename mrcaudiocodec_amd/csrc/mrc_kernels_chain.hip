@@ -763,11 +763,14 @@ __global__ void chain_flush_gather_kernel(int64_t nStreams, int L, const T* __re
 }
 
 // the file header of every stream in front of its first chunk
+// (hdrLen == 0: no headers), and where every stream's bytes start: what the host wants to know without reading the
+// positions of all chunks back
 __global__ void chain_header_kernel(int64_t nStreams, int hdrLen, const unsigned char* __restrict__ hdr,
                                     const long long* __restrict__ firstChunk, const long long* __restrict__ pos,
-                                    unsigned char* __restrict__ out, long long outCap) {
+                                    unsigned char* __restrict__ out, long long outCap, long long* __restrict__ streamPos) {
     const int64_t s = blockIdx.x;
     const long long p0 = pos[firstChunk[s]] - hdrLen;
+    if (threadIdx.x == 0) streamPos[s] = p0;
     if (p0 < 0 || p0 + hdrLen > outCap) return;
     for (int i = threadIdx.x; i < hdrLen; i += blockDim.x) out[p0 + i] = hdr[s * hdrLen + i];
 }
@@ -826,10 +829,11 @@ hipError_t launch_chain_flush_gather(int64_t nStreams, int L, const void* pcmL, 
 }
 
 hipError_t launch_chain_headers(int64_t nStreams, int hdrLen, const unsigned char* hdr, const long long* firstChunk,
-                                const long long* pos, unsigned char* out, long long outCap, hipStream_t st) {
+                                const long long* pos, unsigned char* out, long long outCap, long long* streamPos,
+                                hipStream_t st) {
     if (nStreams <= 0) return hipSuccess;
     hipLaunchKernelGGL(chain_header_kernel, dim3((unsigned)nStreams), dim3(64), 0, st, nStreams, hdrLen, hdr, firstChunk,
-                       pos, out, outCap);
+                       pos, out, outCap, streamPos);
     return hipGetLastError();
 }
 

@@ -490,20 +490,41 @@ __device__ unsigned long long gPhaseCycles[16];
 // immediates; same arithmetic, same results.  0: any shape, dimensions from DevShape.
 // MODE: what the hot paths fix at compile time -- 1: mono (one signal per frame, every band wanted, no thresholds out, band
 // peaks out); 2: joint stereo with the M/S switch known (four signals, the rest alike); 0: all of it at run time.
-template <bool EXACT, class SampleT, int NT, int DIM, int MODE>
-__global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsigArg, const SampleT* __restrict__ chL,
-                                                       const SampleT* __restrict__ chR, int64_t stride,
-                                                       const int64_t* __restrict__ offsetsArg,
-                                                       const double* __restrict__ lines,
-                                                       const int* __restrict__ oscale, double* __restrict__ smr,
-                                                       double* __restrict__ threshArg, double* __restrict__ bandPeakArg,
-                                                       const int* __restrict__ msSwitch, SmrLds layArg) {
+// PLAN5 (long blocks on the hot paths only): the LDS plan that lets FIVE workgroups share a CU instead of four -- 31.6 KB
+// instead of 40.2 KB of dynamic LDS, under a 96-register cap (smr_kernel5).  The 1024-point FFT runs in place (one
+// buffer), and one region of 1024 doubles is handed from the FFT twiddles to the intensity spectrum to the Bark grid to the
+// prefix sums, as each dies:
+//   [0, 2048)     F : FFT data; then the masker table (4 doubles x <= 461 maskers), bandKey / peakKey [1848, 1912),
+//                     ratioKey [1952, 1984), 2^x table [1984, 2048)
+//   [2048, 2561)  C : cntArr, nUpArr (2 x 1026 uint16)
+//   [2561, 3585)  X : twiddle quadrant -> xi (925) -> Bark grid zb (1024) -> piHi, piLo (2 x 462)
+//   [3585, 3713)  Y : log10 table during the masker-table phase (afterwards read from global memory: rare uses only)
+//   [3485, 3947)  sc: suffix sums, after the Bark grid is dead (the tail of X and what Y held)
+// The peak compaction writes each peak's three intensities and its bin into the peak's masker-table slot (no peak-bin array;
+// the spectrum is dead one phase earlier, which is what frees X for the Bark grid).  Same arithmetic, same results.
+constexpr int kP5C = 2048, kP5X = 2561, kP5Y = 3585, kP5Sc = 3485, kP5Total = 3947, kP5Pi = 462;
+constexpr int kP5Keys = 1848;                    // bandKey, peakKey: [1848, 1912), behind the last masker (4 x 462 = 1848)
+static_assert(kP5Keys + 2 * kMaxBands <= 2048 - kExpTab - kMaxBands, "PLAN5: keys overlap ratioKey");
+static_assert(kP5Total * 8 + 128 <= 25 * 1280, "PLAN5: more than a fifth of the CU's LDS");
+
+template <bool EXACT, class SampleT, int NT, int DIM, int MODE, bool PLAN5>
+__device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT* __restrict__ chL,
+                                         const SampleT* __restrict__ chR, int64_t stride,
+                                         const int64_t* __restrict__ offsetsArg, const double* __restrict__ lines,
+                                         const int* __restrict__ oscale, double* __restrict__ smr,
+                                         double* __restrict__ threshArg, double* __restrict__ bandPeakArg,
+                                         const int* __restrict__ msSwitch, SmrLds layArg) {
+    static_assert(!PLAN5 || (DIM == 1024 && !EXACT && MODE != 0 && NT == 256), "PLAN5: long blocks, fast mode, hot paths");
     extern __shared__ double smem[];
-    const SmrLds lay = DIM ? smr_layout(DIM, DIM, DIM - 100, nullptr) : layArg;
+    const SmrLds lay = PLAN5 ? SmrLds{kP5X, kP5Y, kP5X} : DIM ? smr_layout(DIM, DIM, DIM - 100, nullptr) : layArg;
     __shared__ int waveCnt[NT / kWave];
-    __shared__ unsigned long long bandKey[kMaxBands];   // per-band running max of the excess (order-preserving key)
+    // per-band running max of the excess (order-preserving key), per-band max |X| (the bit pattern of |x| orders like |x|).
+    // PLAN5 keeps them in the gap of region F behind the masker table (the LDS of a CU is handed out in 1280-byte granules:
+    // a fifth of it is 25 granules = 32 000 B for dynamic + static together), zeroed once the FFT is done.
+    __shared__ unsigned long long bandKeyS[PLAN5 ? 1 : kMaxBands], peakKeyS[PLAN5 ? 1 : kMaxBands];
+    unsigned long long* const bandKey = PLAN5 ? reinterpret_cast<unsigned long long*>(smem + kP5Keys) : bandKeyS;
+    unsigned long long* const peakKey = PLAN5 ? bandKey + kMaxBands : peakKeyS;
     __shared__ unsigned long long slopeKey[2];          // min / max upper slope over the frame's maskers (keys)
-    __shared__ unsigned long long peakKey[kMaxBands];   // per-band max |X| (the bit pattern of |x| orders like |x|)
     __shared__ unsigned char needBand[kMaxBands];       // joint blocks: does the encoder use THIS signal's SMR of the band?
     const int tid = threadIdx.x;
     const int lane = tid & (kWave - 1), wave = tid >> 6;
@@ -534,14 +555,15 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
     const unsigned unit = (unsigned)(f * nsig + sig);
     const int64_t off = offsets ? offsets[f] : f * stride;
     double2* A = (double2*)smem;                        // [H]
-    double2* B = A + H;                                 // [H]
-    double* xi = smem + 4 * H;                          // [peakLast + 1] intensity spectrum; later the suffix sums
+    double2* B = A + H;                                 // [H]  (PLAN5: not used, the FFT runs in place)
+    double* xi = PLAN5 ? smem + kP5X : smem + 4 * H;    // [peakLast + 1] intensity spectrum; later the suffix sums
     // region B is free once the spectrum is in xi: peak bins, then per-line masker counts (filled below)
-    short* pkBin = reinterpret_cast<short*>(smem + 2 * H);              // [<= peakLast/2 + 1] peak bins, increasing
-    unsigned short* cntArr = reinterpret_cast<unsigned short*>(pkBin + ((last / 2 + 5) & ~3));   // [M + 1]
+    short* pkBin = reinterpret_cast<short*>(smem + 2 * H);              // [<= peakLast/2 + 1] peak bins, increasing (not PLAN5)
+    unsigned short* cntArr = PLAN5 ? reinterpret_cast<unsigned short*>(smem + kP5C)
+                                   : reinterpret_cast<unsigned short*>(pkBin + ((last / 2 + 5) & ~3));   // [M + 1]
     unsigned short* nUpArr = cntArr + (M + 2);                           // [M + 1]
-    double* piHi = reinterpret_cast<double*>(nUpArr + (M + 2));          // [<= peakLast/2 + 2] prefix sums of the masker
-    double* piLo = piHi + (last / 2 + 2);                          //   intensities, double-double (hi, lo)
+    double* piHi = PLAN5 ? smem + kP5X : reinterpret_cast<double*>(nUpArr + (M + 2));   // [<= peakLast/2 + 2] prefix sums of
+    double* piLo = piHi + (PLAN5 ? kP5Pi : last / 2 + 2);                //   the masker intensities, double-double (hi, lo)
 
 #ifdef MRC_PROFILE_PHASES
     long long tPhase_ = clock64();
@@ -550,9 +572,9 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
     // is one long stream of VALU work.  Waves of the four workgroups that share a SIMD are in different phases: the
     // ones in the latency-bound part get issue priority, so their chain is not stretched by a neighbour's sweep.
     __builtin_amdgcn_s_setprio(MRC_FRONT_PRIO);
-    if (tid < kMaxBands) bandKey[tid] = 0ull;           // below every key; visible after the first barrier
+    if (!PLAN5 && tid < kMaxBands) bandKey[tid] = 0ull; // below every key; visible after the first barrier
     if (tid < 2) slopeKey[tid] = tid ? 0ull : ~0ull;
-    if (tid < kMaxBands) peakKey[tid] = 0ull;
+    if (!PLAN5 && tid < kMaxBands) peakKey[tid] = 0ull;
     // ms_stereo.py:70-81 (OverallSMRs) keeps, per band, either the L / R pair of SMRs or the M / S pair: the other two
     // never reach the bit allocation.  With the switch known (it only needs the MDCT lines) the sweep below leaves out
     // the 64-line chunks none of whose bands want this signal -- half of all (signal, band) pairs of a stereo frame.
@@ -562,7 +584,8 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
     const double* e2tab = smem + 2 * H - kExpTab;       // 2^(j/64): the tail of region A, behind the masker table
     // per-band max of (line intensity / masked threshold) as the bit pattern of a positive double; in front of e2tab
     unsigned long long* ratioKey = reinterpret_cast<unsigned long long*>(smem + 2 * H - kExpTab - kMaxBands);
-    const double* logTab = smem + lay.logOff;
+    const double* logTabLds = smem + lay.logOff;        // (PLAN5: valid through the masker-table phase only)
+    const double* logTab = PLAN5 ? kLogTabDev.v : logTabLds;   // the sweep's rare uses and the 25 band conversions
     // Hann window (window.py:28-45) and real FFT through an H = N/2 point complex FFT.  All global loads of a
     // thread are issued before the first use: one memory round trip per phase instead of one per iteration.
     constexpr int kPre = 4;
@@ -607,7 +630,8 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
         __syncthreads();
         MRC_PHASE(0); MRC_STOP(0);
 #ifndef MRC_SMR_FFT8
-        if (LONG && NT == 256) T = fft_lds_1024<NT>(A, B, Wq, tid);
+        if constexpr (PLAN5) { fft_inplace_1024<NT>(A, Wq, tid); T = A; }
+        else if (LONG && NT == 256) T = fft_lds_1024<NT>(A, B, Wq, tid);
         else if (DIM == 128) T = fft_lds_128<NT>(A, B, Wq, tid);
         else
 #endif
@@ -646,14 +670,17 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
     __syncthreads();                                    // T (in A or B) is dead from here on
     MRC_PHASE(2); MRC_STOP(2);
     if (!EXACT) {                                       // stage the Bark grid and the log10 table (used after 2 barriers)
-        double* zw = smem + lay.zbOff;
+        if (!PLAN5) {                                   // (PLAN5: the Bark grid takes xi's place once the peaks are compacted)
+            double* zw = smem + lay.zbOff;
 #pragma unroll
-        for (int u = 0; u < kPre; ++u)
-            if (tid + u * NT < M) zw[tid + u * NT] = zbPre[u];
-        for (int k = tid + kPre * NT; k < M; k += NT) zw[k] = S.zb[k];
+            for (int u = 0; u < kPre; ++u)
+                if (tid + u * NT < M) zw[tid + u * NT] = zbPre[u];
+            for (int k = tid + kPre * NT; k < M; k += NT) zw[k] = S.zb[k];
+        }
         if (tid < kLogTabEntries * 4) smem[lay.logOff + tid] = logPre;
         if (tid < kExpTab) smem[2 * H - kExpTab + tid] = e2Pre;
         if (tid < kMaxBands) ratioKey[tid] = 0ull;
+        if (PLAN5 && tid < 2 * kMaxBands) bandKey[tid] = 0ull;           // (bandKey and peakKey, adjacent)
     }
 
     // tonal maskers: strict 3-point peaks at bins p = 1 .. last-2, kept in increasing bin order.
@@ -679,19 +706,39 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
     // compact the peak bins first (ordered), then one masker per thread: the transcendental-heavy
     // table entry is computed by full waves instead of the few lanes that happen to own a peak
     for (int p = p0; p < p1; ++p)
-        if (xi[p] > xi[p - 1] && xi[p] > xi[p + 1]) pkBin[before++] = (short)p;
+        if (xi[p] > xi[p - 1] && xi[p] > xi[p + 1]) {
+            if (PLAN5) {                                 // the peak's intensities and bin go straight into its table slot
+                double* e = mt + 4 * before++;
+                e[0] = xi[p - 1]; e[1] = xi[p]; e[2] = xi[p + 1]; e[3] = (double)p;
+            } else {
+                pkBin[before++] = (short)p;
+            }
+        }
     if (!EXACT)
         for (int k = tid; k <= M; k += NT) { cntArr[k] = 0; nUpArr[k] = 0; }
     __syncthreads();
+    if (PLAN5) {                                        // xi is dead: its region takes the Bark grid of the lines
+        double* zw = smem + lay.zbOff;
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) zw[tid + u * NT] = zbPre[u];      // (kPre * NT = M = 1024)
+        __syncthreads();
+    }
     MRC_PHASE(3); MRC_STOP(3);
     double slLo = 1e300, slHi = -1e300;                 // this thread's maskers: range of the upper slope
     for (int mi = tid; mi < nPeaks; mi += NT) {
-        const int p = pkBin[mi];
         const int before = mi;
-        double x0 = xi[p - 1], x1 = xi[p], x2 = xi[p + 1];
+        int p;
+        double x0, x1, x2;
+        if (PLAN5) {
+            const double* e = mt + 4 * mi;
+            x0 = e[0]; x1 = e[1]; x2 = e[2]; p = (int)e[3];
+        } else {
+            p = pkBin[mi];
+            x0 = xi[p - 1]; x1 = xi[p]; x2 = xi[p + 1];
+        }
         {
             double s3 = (x0 + x1) + x2;
-            double level = EXACT ? spl_db(s3) : spl_db_tab(s3, logTab);      // psychoac.py:164
+            double level = EXACT ? spl_db(s3) : spl_db_tab(s3, logTabLds);   // psychoac.py:164
             const double fnum = S.binHz * (((p - 1) * x0 + p * x1) + (p + 1) * x2);
             double fm = EXACT ? fnum / s3 : fnum * recip_nr(s3);                  // psychoac.py:165
             // psychoac.py:27-29.  The fast path multiplies by the reciprocals of the constants 7500, 1000 and 10
@@ -792,7 +839,7 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
         }
     } else {
         // suffix sums of the lower-side constants: sc[m] = sum_{j >= m} I_j 2^(b z_j), sc[nPeaks] = 0
-        double* sc = xi;                                // xi is dead (all peak reads happened before the barrier)
+        double* sc = PLAN5 ? smem + kP5Sc : xi;         // xi is dead (all peak reads happened before the barrier)
         // four independent scans, dealt to the workgroup's waves (4 waves: one each; 2 waves: two each)
         for (int task = wave; task < 4; task += NT / kWave) {
         if (task == 0) {
@@ -1160,7 +1207,39 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
     }
 }
 
+template <bool EXACT, class SampleT, int NT, int DIM, int MODE>
+__global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsigArg, const SampleT* __restrict__ chL,
+                                                       const SampleT* __restrict__ chR, int64_t stride,
+                                                       const int64_t* __restrict__ offsetsArg,
+                                                       const double* __restrict__ lines,
+                                                       const int* __restrict__ oscale, double* __restrict__ smr,
+                                                       double* __restrict__ threshArg, double* __restrict__ bandPeakArg,
+                                                       const int* __restrict__ msSwitch, SmrLds layArg) {
+    smr_body<EXACT, SampleT, NT, DIM, MODE, false>(S, nsigArg, chL, chR, stride, offsetsArg, lines, oscale, smr, threshArg,
+                                                   bandPeakArg, msSwitch, layArg);
+}
+
+// the long block of the hot paths under PLAN5: five workgroups of four waves per CU (<= 96 VGPRs, 31.6 KB of LDS)
+template <class SampleT, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void smr_kernel5(
+    DevShape S, const SampleT* __restrict__ chL, const SampleT* __restrict__ chR, int64_t stride,
+    const int64_t* __restrict__ offsetsArg, const double* __restrict__ lines, const int* __restrict__ oscale,
+    double* __restrict__ smr, double* __restrict__ bandPeakArg, const int* __restrict__ msSwitch) {
+    smr_body<false, SampleT, 256, 1024, MODE, true>(S, MODE == 1 ? 1 : 4, chL, chR, stride, offsetsArg, lines, oscale, smr,
+                                                    nullptr, bandPeakArg, msSwitch, SmrLds{0, 0, 0});
+}
+
 }  // namespace
+
+#ifdef MRC_DEBUG_OCC                             // experiment aid: workgroups per CU the runtime grants the long-block kernels
+extern "C" int mrc_debug_smr_occupancy(int* out2) {
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&out2[0], smr_kernel5<short, 1>, 256, (size_t)kP5Total * 8);
+    if (e == hipSuccess)
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&out2[1], smr_kernel<false, short, 256, 1024, 1>, 256,
+                                                         (size_t)(4 * 1024 + 925) * 8);
+    return e == hipSuccess ? 0 : -1;
+}
+#endif
 
 #ifdef MRC_PROFILE_PHASES
 extern "C" int mrc_debug_phase_cycles(unsigned long long* out16, int reset) {
@@ -1202,6 +1281,23 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
     const bool isTrans = H == 576 && M == 576 && S.peakLast == 476 && lay.twOff < 0 && MRC_SMR_THREADS == 256;
     // the hot paths: mono, and (long blocks) joint stereo with the switch known; no thresholds wanted
     const int mode = (thresh || !bandPeak) ? 0 : (nsig == 1 && !msSwitch) ? 1 : (nsig == 4 && msSwitch) ? 2 : 0;
+// MRC_SMR_PLAN5=1: long blocks of the hot paths run smr_kernel5 (5 workgroups per CU; the runtime's occupancy query confirms
+// the fifth).  Measured, round 3: 4.567 vs 4.548 ms per 131 072 mono frames, 9.32 vs 9.07 ms per joint step of 65 536 -- the
+// fifth workgroup buys nothing (the kernel is bound by VALU issue, and the 96-register cap and the extra barriers of the
+// in-place FFT cost what the occupancy gives), so the four-workgroup plan stays the default.  Results are identical.
+#ifndef MRC_SMR_PLAN5
+#define MRC_SMR_PLAN5 0
+#endif
+#define MRC_SMR_LAUNCH5(TY, MD)                                                                                       \
+    hipLaunchKernelGGL((smr_kernel5<TY, MD>), grid, dim3(256), (size_t)kP5Total * sizeof(double), st, S, (const TY*)chL, \
+                       (const TY*)chR, stride, offsets, lines, oscale, smr, bandPeak, msSwitch)
+    const bool plan5 = MRC_SMR_PLAN5 && isLong && !exactSpread && mode != 0 && S.nBands <= kMaxBands;
+    if (plan5) {
+        if (fmt == kSampleI16) { if (mode == 1) MRC_SMR_LAUNCH5(short, 1); else MRC_SMR_LAUNCH5(short, 2); }
+        else { if (mode == 1) MRC_SMR_LAUNCH5(double, 1); else MRC_SMR_LAUNCH5(double, 2); }
+        return hipGetLastError();
+    }
+#undef MRC_SMR_LAUNCH5
 #define MRC_SMR_PICK(EX, TY) do { if (isShort && !EX && mode == 1) MRC_SMR_LAUNCH(EX, TY, 128, 128, 1);               \
                                   else if (isShort && !EX) MRC_SMR_LAUNCH(EX, TY, 128, 128, 0);                      \
                                   else if (M <= 2 * kWave) MRC_SMR_LAUNCH(EX, TY, 128, 0, 0);                        \

@@ -151,3 +151,20 @@ def test_argument_checks(h):
     with pytest.raises(MrcError):                                       # Close() needs a long last block
         h.encode_chained_pac(stream[0][None], stream[1][None], [[(0, 1024, 128)]], with_flush=True)
 
+
+
+def test_item_offsets_are_optional_and_consistent(h):
+    # want_items: where every block's chunk pair starts (read back from the packer's positions); without it only the
+    # stream starts come back (gathered on the device)
+    stream, shapes = _switching_stream(hops=9, seed=2)
+    two = np.stack([stream, 0.5 * stream])
+    ns = [shapes[-1][0] + shapes[-1][1]] * 2
+    a = h.encode_chained_pac(two[:, 0], two[:, 1], [shapes, shapes], num_samples=ns, want_items=True)
+    b = h.encode_chained_pac(two[:, 0], two[:, 1], [shapes, shapes], num_samples=ns)
+    assert b["item_offset"] is None and a["bytes"].tobytes() == b["bytes"].tobytes()
+    assert np.array_equal(a["stream_offset"], b["stream_offset"])
+    n_items = len(shapes) + 2
+    io = a["item_offset"]
+    assert len(io) == 2 * n_items + 1 and np.all(np.diff(io) > 0) and io[-1] == a["total"]
+    hdr = int(io[0] - a["stream_offset"][0])
+    assert hdr > 0 and io[n_items] - hdr == a["stream_offset"][1]      # the header sits between the stream start and item 0

@@ -117,3 +117,38 @@ def test_detector_on_int16_codes_equals_detector_on_floats():
         assert np.array_equal(ptr.block_shape_array(h, codes, sos), np.asarray(ptr.block_shapes(h, synth.pcm_to_float(codes), sos)))
     finally:
         h.close()
+
+
+@pytest.mark.gpu
+def test_detector_kernel_forms_agree_with_sosfilt():
+    # the kernel has a specialised form (ten sections = the reference's cheby2(20, ...), hops on 16-byte boundaries,
+    # coefficients in registers, samples eight / two per load) and a general one; both must give sosfilt's peaks --
+    # for other section counts, and for a device stream that starts on an odd sample (dev entry point)
+    import torch
+    from scipy import signal
+    from mrcaudiocodec_amd import Handle
+    h = Handle(device_id=0)
+    try:
+        s = _stereo_stream(12)
+        for order in (20, 6, 2, 32):
+            sos = ptr.design_sos(48000) if order == 20 else signal.cheby2(order, 40, 9000.0 / 48000, "high", output="sos")
+            got = h.transient_peaks(s, sos)
+            want = _scipy_peaks(s, sos)
+            assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max(), order
+        sos = ptr.design_sos(48000)
+        want = _scipy_peaks(s[:1], sos)
+        for dtype, fmt in ((torch.float64, 0), (torch.int16, 1)):
+            x = s[0] if fmt == 0 else np.clip(np.rint(s[0] * 32767), -32767, 32767).astype(np.int16)
+            ref = _scipy_peaks(synth.pcm_to_float(x)[None], sos) if fmt else want
+            buf = torch.zeros(len(x) + 8, dtype=dtype, device="cuda:0")
+            for shift in (0, 1, 3):                                   # 0: aligned (specialised form); 1, 3: general form
+                buf[shift:shift + len(x)] = torch.from_numpy(x).to("cuda:0")
+                view = buf[shift:shift + len(x)]
+                n_hops = len(x) // 1024 - 1
+                peaks = torch.empty((n_hops, 1, 9), dtype=torch.float64, device="cuda:0")
+                h.dev_transient_peaks(n_hops, 1, sos, view.data_ptr(), fmt, len(x), peaks.data_ptr(),
+                                      torch.cuda.current_stream().cuda_stream)
+                torch.cuda.synchronize()
+                assert np.abs(peaks.cpu().numpy() - ref).max() <= 1e-13 * np.abs(ref).max(), (fmt, shift)
+    finally:
+        h.close()
