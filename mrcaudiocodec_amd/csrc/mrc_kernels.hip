@@ -10,6 +10,8 @@
 // specialisations for the long block live in mrc_kernels_long.hip.
 #include "mrc_device.hpp"
 
+#include <algorithm>
+
 namespace mrc {
 using namespace dev;
 namespace {
@@ -74,6 +76,219 @@ __global__ __launch_bounds__(NT) void mdct_kernel(DevShape S, int nsig, const Sa
     if (tid == 0) {
         for (int w = 1; w < NT / kWave; ++w) peak = fmax(peak, red[w]);
         oscale[blockIdx.x] = scale_factor_dev(peak, S.nScaleBits, 5);       // codecThem.py:322 (nMantBits default)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MDCT of the short (128 + 128) and transition (1024 + 128, 128 + 1024) blocks of the reference's block switching: ONE
+// WAVEFRONT per group of U units, no workgroup barrier inside the loop.  Same transform and formulas as mdct_kernel above.
+// What mdct_kernel costs on these shapes is instructions, not bytes: its passes run Q / R butterflies on NT threads (16 of 64
+// lanes busy for a short block's radix-4 passes, 72 of 256 threads for a transition block), with run-time radices, strides
+// and divisions -- ~1 500 instructions per wave and unit -- and every unit re-reads ~5 KB of window / twiddle constants
+// through a chain of dependent loads.  Here
+//   * U units share a wave so that its lanes are busy: four short blocks give 4 x 16 = 64 radix-4 butterflies per pass; a
+//     transition block's 288-point FFT runs as 8 x 4 x 3 x 3 in 1 + 2 + 2 + 2 rounds of 64 lanes;
+//   * every size is a template parameter (index splits and twiddle strides fold into immediates);
+//   * the window values and pre- / post-twiddles of a lane's sample and point slots live in registers and the FFT's twiddle
+//     table in LDS, loaded once per workgroup, which then walks `run` groups per wave;
+//   * a unit's samples come as coalesced loads of 64 consecutive samples (N is a multiple of 64, so a load never straddles two
+//     units and the unit of a slot is wave-uniform: offsets and signal ids stay scalar).
+// ------------------------------------------------------------------------------------------------
+struct TwLds {
+    const double2* w;                                   // LDS, [n]
+    __device__ __forceinline__ double2 operator()(int t, int /*nq*/) const { return w[t]; }
+};
+// LDS traffic between lanes of ONE wave: order the wave's own DS operations and keep the compiler from moving LDS accesses
+// across this point
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// one Stockham pass of radix R over U transforms of Q points each (P = product of the radices already done), a butterfly
+// per lane and round
+template <int R, int Q, int P, int U>
+__device__ __forceinline__ void wave_pass(const double2* in, double2* out, const double2* wl, int lane) {
+    constexpr int T = Q / R, tws = Q / (P * R), total = U * T;
+#pragma unroll
+    for (int b0 = 0; b0 < total; b0 += kWave) {
+        const int b = b0 + lane;
+        if (b0 + kWave <= total || b < total) {
+            const int unit = b / T, i = b % T;
+            const int k = i % P, j = (i / P) * (P * R) + k;
+            const double2* src = in + unit * Q;
+            double2* dst = out + unit * Q;
+            double2 u[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) u[r] = src[i + r * T];
+            if (P != 1) {
+#pragma unroll
+                for (int r = 1; r < R; ++r) u[r] = cmul(u[r], wl[k * r * tws]);
+            }
+            butterfly<R>(u);
+#pragma unroll
+            for (int q = 0; q < R; ++q) dst[j + q * P] = u[q];
+        }
+    }
+}
+// the passes of the two sizes; returns the buffer that holds the natural-order result
+template <int Q, int U>
+__device__ __forceinline__ double2* wave_fft(double2* A, double2* B, const double2* wl, int lane) {
+    static_assert(Q == 64 || Q == 288, "sizes of the reference's short and transition blocks");
+    if (Q == 64) {
+        wave_pass<4, Q, 1, U>(A, B, wl, lane);
+        wave_sync();
+        wave_pass<4, Q, 4, U>(B, A, wl, lane);
+        wave_sync();
+        wave_pass<4, Q, 16, U>(A, B, wl, lane);
+        wave_sync();
+        return B;
+    }
+    wave_pass<8, Q, 1, U>(A, B, wl, lane);
+    wave_sync();
+    wave_pass<4, Q, 8, U>(B, A, wl, lane);
+    wave_sync();
+    wave_pass<3, Q, 32, U>(A, B, wl, lane);
+    wave_sync();
+    wave_pass<3, Q, 96, U>(B, A, wl, lane);
+    wave_sync();
+    return A;
+}
+
+constexpr int kMdctWaves = 4;                           // waves per workgroup, each with its own groups of units
+constexpr int kMdctMaxRun = 8;                          // groups per wave, at most
+template <class SampleT, int N, int U, int NSIG>
+__global__ __launch_bounds__(kWave * kMdctWaves, 2) void mdct_wave_kernel(
+    DevShape S, int64_t nUnits, int run, const SampleT* __restrict__ chL, const SampleT* __restrict__ chR, int64_t stride,
+    const int64_t* __restrict__ offsets, double* __restrict__ lines, int* __restrict__ oscale) {
+    constexpr int Q = N / 4, M = N / 2;
+    constexpr int kSlots = U * N / kWave;                // sample slots per lane: s = lane + 64 c, unit c / (N / 64)
+    constexpr int kSlotsPerUnit = N / kWave;
+    constexpr int kPoints = (U * Q + kWave - 1) / kWave; // FFT points per lane: g = lane + 64 c
+    // doubles per wave: y [U][N] (windowed samples; dead after the fold, then the FFT's second buffer B [U][Q] complex and,
+    // for the sizes whose result ends in A, the staging of the output lines) | A [U][Q] complex (and the staging otherwise)
+    constexpr int kWaveLds = U * N + 2 * U * Q;
+    static_assert(N % kWave == 0 && ((U * Q) % kWave == 0 || U == 1), "a slot never straddles two units");
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    double* y = smem + wave * kWaveLds;
+    double2* A = reinterpret_cast<double2*>(y + U * N);
+    double2* B = reinterpret_cast<double2*>(y);
+    double2* wl = reinterpret_cast<double2*>(smem + kMdctWaves * kWaveLds);          // [Q] e^{-2 pi i t/Q}
+    __shared__ long long sOff[kMdctWaves][kMdctMaxRun * U];                          // sample offset of every unit of a wave's run
+    for (int t = threadIdx.x; t < Q; t += kWave * kMdctWaves) wl[t] = S.wQ[t];
+    // lane constants: window value of every sample slot and where the sample goes after the signed circular shift by
+    // (b-a)/4 (see mdct_kernel; bit 31: negated); pre- and post-twiddle of every point slot
+    double wv[kSlots];
+    unsigned dst[kSlots];
+#pragma unroll
+    for (int c = 0; c < kSlots; ++c) {
+        const int n = lane + kWave * (c % kSlotsPerUnit);
+        wv[c] = S.win[n];
+        int m = n + S.shift;
+        unsigned neg = 0;
+        if (m < 0) { m += N; neg = 1u << 31; }
+        else if (m >= N) { m -= N; neg = 1u << 31; }
+        dst[c] = (unsigned)(m + (c / kSlotsPerUnit) * N) | neg;
+    }
+    double2 preR[kPoints], postR[kPoints];
+#pragma unroll
+    for (int c = 0; c < kPoints; ++c) {
+        const int n = min((lane + kWave * c) % Q, Q - 1);
+        preR[c] = S.pre[n];
+        postR[c] = S.post[n];
+    }
+    __syncthreads();                                    // twiddle table visible to all waves
+
+    const int64_t firstGroup = ((int64_t)blockIdx.x * kMdctWaves + wave) * run;
+    // the sample offsets of all units of this wave's run, fetched at once (a scalar load per group inside the loop would put
+    // a memory round trip in front of every group's sample loads)
+    if (lane < run * U) {
+        const int64_t unit = min(firstGroup * U + lane, nUnits - 1);                 // (the tail repeats the last unit)
+        const int64_t f = NSIG == 1 ? unit : unit / NSIG;
+        sOff[wave][lane] = offsets ? offsets[f] : f * stride;
+    }
+    wave_sync();
+    // raw samples of the group in flight: requested one group ahead, converted when their group starts.  Coalesced: 64
+    // consecutive samples of one unit per load; a joint group needs both channels (its units are consecutive signals of the
+    // same frames).
+    SampleT rawL[kSlots], rawR[NSIG == 1 ? 1 : kSlots];
+    auto request = [&](int it) {
+#pragma unroll
+        for (int c = 0; c < kSlots; ++c) {
+            const int64_t i = sOff[wave][it * U + c / kSlotsPerUnit] + lane + kWave * (c % kSlotsPerUnit);
+            rawL[c] = chL[i];
+            if (NSIG != 1) rawR[c] = chR[i];
+        }
+    };
+    if (firstGroup * U < nUnits) request(0);
+    for (int it = 0; it < run; ++it) {
+        const int64_t u0 = (firstGroup + it) * U;
+        if (u0 >= nUnits) break;                        // wave-uniform
+        // ---- A. convert, window, shift
+#pragma unroll
+        for (int c = 0; c < kSlots; ++c) {
+            const int sig = NSIG == 1 ? 0 : (int)(min(u0 + c / kSlotsPerUnit, nUnits - 1) % NSIG);
+            double v;
+            if (NSIG == 1 || sig == 0) v = sample_of(&rawL[c], 0);
+            else if (sig == 1) v = sample_of(&rawR[NSIG == 1 ? 0 : c], 0);
+            else {
+                const double l = sample_of(&rawL[c], 0), r = sample_of(&rawR[NSIG == 1 ? 0 : c], 0);   // codecThem.py:363-364
+                v = sig == 2 ? (l + r) / 2.0 : (l - r) / 2.0;
+            }
+            const double x = v * wv[c];
+            y[dst[c] & 0x7fffffffu] = (dst[c] >> 31) ? -x : x;
+        }
+        if (it + 1 < run && u0 + U < nUnits) request(it + 1);          // in flight while this group is transformed
+        wave_sync();
+        // ---- B. fold N -> N/2 (DCT-IV input u) and pack pairs into Q complex points with the pre-twiddle
+#pragma unroll
+        for (int c = 0; c < kPoints; ++c) {
+            const int g = lane + kWave * c;
+            if ((c + 1) * kWave <= U * Q || g < U * Q) {
+                const int ug = g / Q, n = g % Q;
+                const double* yu = y + ug * N;
+                const int j0 = 2 * n, j1 = M - 1 - 2 * n, h = Q;
+                const double u0v = (j0 < h) ? (-yu[3 * h - 1 - j0] - yu[3 * h + j0]) : (yu[j0 - h] - yu[3 * h - 1 - j0]);
+                const double u1v = (j1 < h) ? (-yu[3 * h - 1 - j1] - yu[3 * h + j1]) : (yu[j1 - h] - yu[3 * h - 1 - j1]);
+                A[g] = cmul(make_double2(u0v, u1v), preR[c]);
+            }
+        }
+        wave_sync();
+        // ---- C. U transforms of Q points
+        const double2* T = wave_fft<Q, U>(A, B, wl, lane);
+        // ---- D. post-twiddle into the buffer the result is not in (U x M doubles): X[2k] = (2/N) Re, X[N/2-1-2k] = -(2/N) Im
+        double* stage = (T == A) ? y : reinterpret_cast<double*>(A);
+#pragma unroll
+        for (int c = 0; c < kPoints; ++c) {
+            const int g = lane + kWave * c;
+            if ((c + 1) * kWave <= U * Q || g < U * Q) {
+                const int ug = g / Q, k = g % Q;
+                const double2 cc = cmul(T[g], postR[c]);
+                double* xu = stage + ug * M;
+                xu[2 * k] = S.twoOverN * cc.x;
+                xu[M - 1 - 2 * k] = S.twoOverN * (-cc.y);
+            }
+        }
+        wave_sync();
+        // ---- E. lines out (512 contiguous bytes per store), overall scale per unit (codecThem.py:321-322)
+#pragma unroll
+        for (int uu = 0; uu < U; ++uu) {
+            const int64_t unit = u0 + uu;
+            if (unit >= nUnits) break;                  // wave-uniform
+            double peak = 0.0;
+            double* out = lines + unit * M;
+#pragma unroll
+            for (int c = 0; c < M / kWave; ++c) {
+                const double x = stage[uu * M + lane + kWave * c];
+                out[lane + kWave * c] = x;
+                peak = fmax(peak, fabs(x));
+            }
+            peak = wave_max(peak);
+            if (lane == 0) oscale[unit] = scale_factor_dev(peak, S.nScaleBits, 5);
+        }
+        wave_sync();                                    // staging read before the next group overwrites it
     }
 }
 
@@ -317,6 +532,29 @@ hipError_t launch_mdct(const DevShape& S, int64_t nFrames, const void* chL, cons
     if (applyWindow && !(reinterpret_cast<uintptr_t>(lines) & 15) && mdct_long_applicable(S, stride, offsets, chL, chR, fmt))
         return launch_mdct_long(S, nFrames, chL, chR, fmt, stride, offsets, lines, oscale, st);
     const int nsig = chR ? 4 : 1;
+    // the other shapes of the reference's block switching (short 128 + 128: four units per wavefront at a time; transitions
+    // 1024 + 128 and 128 + 1024: one), windowed: mdct_wave_kernel.  The run length trades the once-per-workgroup constants
+    // against the number of workgroups.
+    if (applyWindow && (S.N == 256 || S.N == 1152)) {
+        const int64_t nUnits = nFrames * nsig;
+        const int U = S.N == 256 ? 4 : 1;
+        const int64_t groups = (nUnits + U - 1) / U;
+        const int run = (int)std::min<int64_t>(kMdctMaxRun, std::max<int64_t>(1, groups / (kMdctWaves * 1024)));
+        const unsigned grid = (unsigned)((groups + (int64_t)kMdctWaves * run - 1) / ((int64_t)kMdctWaves * run));
+        const size_t ldsW = (size_t)(kMdctWaves * (U * S.N + 2 * U * S.Q) + 2 * S.Q) * sizeof(double);
+#define MRC_MDCT_WAVE(TY, NN, UU, NS)                                                                                  \
+    hipLaunchKernelGGL((mdct_wave_kernel<TY, NN, UU, NS>), dim3(grid), dim3(kWave * kMdctWaves), ldsW, st, S, nUnits, run, \
+                       (const TY*)chL, (const TY*)chR, stride, offsets, lines, oscale)
+#define MRC_MDCT_WAVE_T(TY)                                                                                            \
+    do {                                                                                                               \
+        if (S.N == 256) { if (nsig == 1) MRC_MDCT_WAVE(TY, 256, 4, 1); else MRC_MDCT_WAVE(TY, 256, 4, 4); }            \
+        else { if (nsig == 1) MRC_MDCT_WAVE(TY, 1152, 1, 1); else MRC_MDCT_WAVE(TY, 1152, 1, 4); }                     \
+    } while (0)
+        if (fmt == kSampleI16) MRC_MDCT_WAVE_T(short); else MRC_MDCT_WAVE_T(double);
+#undef MRC_MDCT_WAVE_T
+#undef MRC_MDCT_WAVE
+        return hipGetLastError();
+    }
     size_t lds = (size_t)(2 * S.N) * sizeof(double);
     // a short block (N <= 256: 64 complex FFT points) is one wavefront's work; longer ones take four
 #define MRC_MDCT_LAUNCH(TY, THREADS)                                                                                  \

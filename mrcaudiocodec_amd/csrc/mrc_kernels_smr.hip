@@ -466,8 +466,12 @@ __device__ unsigned long long gPhaseCycles[16];
 #ifndef MRC_SMR_WAVES_PER_EU                     // 4 workgroups of 4 waves per CU (what the LDS footprint allows): <= 128 VGPRs
 #define MRC_SMR_WAVES_PER_EU 4
 #endif
+#ifndef MRC_SMR_WAVES_PER_EU_SHORT               // short blocks (two waves, ~5 KB of LDS per workgroup): latency-bound, more waves
+#define MRC_SMR_WAVES_PER_EU_SHORT 8
+#endif
 #if MRC_SMR_WAVES_PER_EU > 0
-#define MRC_SMR_OCC __attribute__((amdgpu_waves_per_eu(MRC_SMR_WAVES_PER_EU, MRC_SMR_WAVES_PER_EU)))
+#define MRC_SMR_OCC __attribute__((amdgpu_waves_per_eu(DIM == 128 ? MRC_SMR_WAVES_PER_EU_SHORT : MRC_SMR_WAVES_PER_EU, \
+                                                       DIM == 128 ? MRC_SMR_WAVES_PER_EU_SHORT : MRC_SMR_WAVES_PER_EU)))
 #else
 #define MRC_SMR_OCC
 #endif
@@ -1042,7 +1046,10 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
             }
         }
 #else
-        for (int u = 0; u < 4; ++u) {
+        // (a block of DIM lines has at most (DIM - 101) / 2 maskers: a short block's 13 never reach kFarMinMaskers, so its
+        // instance carries no far-field code -- and fits the registers of eight waves per SIMD)
+        constexpr bool kHaveFar = DIM == 0 || (DIM - 101) / 2 >= kFarMinMaskers;
+        for (int u = 0; kHaveFar && u < 4; ++u) {
             const int c = chunk_of(i0 + u);
             if (c >= nChunks) break;
             const int kc = min(c * kWave + lane, M - 1);
