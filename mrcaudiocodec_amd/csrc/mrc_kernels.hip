@@ -521,6 +521,90 @@ __global__ __launch_bounds__(kWave) void ms_switch_kernel(int nBands, int nLeave
     }
 }
 
+// The same sums with NO staging and every load of a leaf round in flight at once: a wavefront per block, four blocks per
+// workgroup.  The staged form above holds 16.5 KB of LDS per wavefront -- nine wavefronts per CU, each walking its leaves
+// step by step (load -> add -> load ...): latency-bound at 38 % of the HBM rate.  Here a lane's <= 16 strided elements and
+// <= 7 trailing elements of a leaf are requested together (predicated loads, no requests from idle lanes), the sums run over
+// registers in NumPy's order, and the only LDS is the 64 node sums per wave.
+constexpr int kMsWaves = 4;
+constexpr int kMsMaxSteps = 16, kMsRounds = 8;          // leaf <= 128 lines; <= 64 leaves, eight per round
+template <int CTRL> __device__ __forceinline__ double dpp_from(double v) {           // lane i reads lane i + (CTRL - 0x100) of its row
+    return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false),
+                            __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false));
+}
+__global__ __launch_bounds__(kWave * kMsWaves) void ms_switch_direct_kernel(int64_t nBlocks, int nBands, int nLeaves,
+                                                                             int nInternal, const int* __restrict__ plan,
+                                                                             const double* __restrict__ L,
+                                                                             const double* __restrict__ R, int64_t blockStride,
+                                                                             int* __restrict__ out) {
+    __shared__ double sumD[kMsWaves][64], sumS[kMsWaves][64];
+    const int lane = threadIdx.x & (kWave - 1), g = lane >> 3, j = lane & 7;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t blk = (int64_t)blockIdx.x * kMsWaves + wave;
+    if (blk >= nBlocks) return;                         // (wave-uniform; no workgroup barrier below)
+    const double* l = L + blk * blockStride;
+    const double* r = R + blk * blockStride;
+    // everything the plan says is requested up front: this lane's leaf of every round, the internal node of lane q
+    // (children), the root of band `lane`
+    int lo[kMsRounds], cnt[kMsRounds];
+#pragma unroll
+    for (int q = 0; q < kMsRounds; ++q) {
+        const int t = 8 * q + g;
+        const bool have = t < nLeaves;
+        lo[q] = have ? plan[2 * t] : 0;
+        cnt[q] = have ? plan[2 * t + 1] : 0;
+    }
+    const int* inner = plan + 2 * nLeaves;
+    const int childA = lane < nInternal ? inner[2 * lane] : 0, childB = lane < nInternal ? inner[2 * lane + 1] : 0;
+    const int root = lane < nBands ? plan[2 * nLeaves + 2 * nInternal + lane] : 0;
+    auto dOf = [](double a, double b) { return fabs(a * a - b * b); };
+    auto sOf = [](double a, double b) { return fabs(a * a + b * b); };
+#pragma unroll
+    for (int q = 0; q < kMsRounds; ++q) {
+        if (8 * q >= nLeaves) break;                    // wave-uniform
+        const int n = cnt[q];
+        const int steps = n >> 3, body = n & ~7, tail = n & 7;
+        double lv[kMsMaxSteps], rv[kMsMaxSteps];
+#pragma unroll
+        for (int i = 0; i < kMsMaxSteps; ++i) {
+            lv[i] = 0.0; rv[i] = 0.0;
+            if (i < steps) { lv[i] = l[lo[q] + 8 * i + j]; rv[i] = r[lo[q] + 8 * i + j]; }
+        }
+        // the < 8 trailing lines of the leaf: lane j holds line body + j
+        double lt = 0.0, rt = 0.0;
+        if (j < tail) { lt = l[lo[q] + body + j]; rt = r[lo[q] + body + j]; }
+        // NumPy's eight strided accumulators of the leaf (lane j holds r[j]), combined in its fixed order; a leaf of fewer
+        // than eight lines has none (its sum starts from the 0.0 of np.sum's plain loop: 0.0 + x is x for x >= +0)
+        double d = dOf(lv[0], rv[0]), sg = sOf(lv[0], rv[0]);
+#pragma unroll
+        for (int i = 1; i < kMsMaxSteps; ++i)
+            if (i < steps) { d += dOf(lv[i], rv[i]); sg += sOf(lv[i], rv[i]); }
+        d += dpp_move<0xB1>(d);   sg += dpp_move<0xB1>(sg);       // r0+r1, r2+r3, ...   (quad_perm [1,0,3,2])
+        d += dpp_move<0x4E>(d);   sg += dpp_move<0x4E>(sg);       // (r0+r1)+(r2+r3), ... (quad_perm [2,3,0,1])
+        d += dpp_move<0x141>(d);  sg += dpp_move<0x141>(sg);      // + the other quad     (row_half_mirror)
+        // ... then the trailing lines one by one, in order: lane 0 of the leaf's eight takes them from its neighbours
+        const double dt = dOf(lt, rt), st = sOf(lt, rt);
+#define MRC_MS_TAIL(T)                                                                  \
+        {                                                                               \
+            const double a = T ? dpp_from<0x100 + (T ? T : 1)>(dt) : dt, b = T ? dpp_from<0x100 + (T ? T : 1)>(st) : st;   \
+            if (T < tail) { d += a; sg += b; }                                          \
+        }
+        MRC_MS_TAIL(0) MRC_MS_TAIL(1) MRC_MS_TAIL(2) MRC_MS_TAIL(3) MRC_MS_TAIL(4) MRC_MS_TAIL(5) MRC_MS_TAIL(6)
+#undef MRC_MS_TAIL
+        if (j == 0 && 8 * q + g < nLeaves) { sumD[wave][8 * q + g] = d; sumS[wave][8 * q + g] = sg; }
+    }
+    wave_sync();
+    // internal nodes (bands of more than 128 lines) in tree order: children before parents, so node q waits for q - 1
+    for (int q = 0; q < nInternal; ++q) {
+        if (lane == q) {
+            sumD[wave][nLeaves + q] = sumD[wave][childA] + sumD[wave][childB];
+            sumS[wave][nLeaves + q] = sumS[wave][childA] + sumS[wave][childB];
+        }
+        wave_sync();
+    }
+    if (lane < nBands) out[blk * nBands + lane] = sumD[wave][root] < 0.8 * sumS[wave][root] ? 1 : 0;
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -648,6 +732,14 @@ hipError_t launch_ms_switch(int64_t nBlocks, int nBands, int nLeaves, int nInter
     if (nBlocks <= 0) return hipSuccess;
     const bool staged = nLines > 0 && nLines <= kMsStageLines && !(nLines & 1) && !(blockStride & 1) &&
                         !((reinterpret_cast<uintptr_t>(L) | reinterpret_cast<uintptr_t>(R)) & 15);
+#ifndef MRC_MS_DIRECT                            // 1: ms_switch_direct_kernel (no staging, a leaf round's loads in flight at once)
+#define MRC_MS_DIRECT 1
+#endif
+    if (MRC_MS_DIRECT && nLeaves <= 8 * kMsRounds) {
+        hipLaunchKernelGGL(ms_switch_direct_kernel, dim3((unsigned)((nBlocks + kMsWaves - 1) / kMsWaves)), dim3(kWave * kMsWaves),
+                           0, st, nBlocks, nBands, nLeaves, nInternal, plan, L, R, blockStride, out);
+        return hipGetLastError();
+    }
     if (staged)
         hipLaunchKernelGGL(ms_switch_kernel<true>, dim3((unsigned)nBlocks), dim3(kWave), 0, st, nBands, nLeaves, nInternal,
                            nLines, plan, L, R, blockStride, out);

@@ -4,6 +4,7 @@
 // (a, b, sampleRate, nScaleBits, nMantSizeBits, targetBitsPerSample, blksw bits).
 #include "mrc_internal.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -150,9 +151,15 @@ void ms_plan(const std::vector<int>& bandLo, const std::vector<int>& bandN, std:
     std::vector<int> roots;
     for (size_t b = 0; b < bandN.size(); ++b) roots.push_back(rec.build(bandLo[b], bandN[b]));
     const int nl = (int)leaves.size();
-    auto id = [nl](int ref) { return ref >= 0 ? ref : nl + (-ref - 1); };
+    // the kernels take the leaves eight at a time, a round lasting as long as its longest leaf: longest first, so that the
+    // rounds are as even as they can be (the order of the LEAVES is free: every sum keeps its own order of additions)
+    std::vector<int> order(nl), newId(nl);
+    for (int i = 0; i < nl; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return leaves[x].second > leaves[y].second; });
+    for (int i = 0; i < nl; ++i) newId[order[i]] = i;
+    auto id = [nl, &newId](int ref) { return ref >= 0 ? newId[ref] : nl + (-ref - 1); };
     plan->clear();
-    for (auto& lf : leaves) { plan->push_back(lf.first); plan->push_back(lf.second); }
+    for (int i = 0; i < nl; ++i) { plan->push_back(leaves[order[i]].first); plan->push_back(leaves[order[i]].second); }
     for (auto& in : rec.pending) { plan->push_back(id(in.first)); plan->push_back(id(in.second)); }
     for (int r : roots) plan->push_back(id(r));
     *nLeaves = nl;
