@@ -557,6 +557,15 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     const int sig = (int)((slot + f) % nsig);
 #endif
     const unsigned unit = (unsigned)(f * nsig + sig);
+    // A joint unit NONE of whose bands the M/S switch selects (all bands M/S: the L and R units; all bands L/R: the M and S
+    // units -- the rule for strongly correlated and for unrelated channels) has no reader at all: neither its SMRs nor its band
+    // peaks reach the bit allocation or the scale factors (ms_stereo.py:70-81; mrc_kernels_alloc.hip reads the selected
+    // signal of every band only).  It ends here, before its first load; its outputs stay unwritten.  Every wave takes the
+    // same decision from the same 25 flags: no barrier.
+    if (haveSwitch && !thresh) {
+        const bool need = lane < S.nBands && ((sig >= 2) == (msSwitch[f * S.nBands + lane] != 0));
+        if (!__any(need)) return;
+    }
     const int64_t off = offsets ? offsets[f] : f * stride;
     double2* A = (double2*)smem;                        // [H]
     double2* B = A + H;                                 // [H]  (PLAN5: not used, the FFT runs in place)
