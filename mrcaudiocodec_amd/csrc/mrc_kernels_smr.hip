@@ -466,8 +466,11 @@ __device__ unsigned long long gPhaseCycles[16];
 #ifndef MRC_SMR_WAVES_PER_EU                     // 4 workgroups of 4 waves per CU (what the LDS footprint allows): <= 128 VGPRs
 #define MRC_SMR_WAVES_PER_EU 4
 #endif
-#ifndef MRC_SMR_WAVES_PER_EU_SHORT               // short blocks (two waves, ~5 KB of LDS per workgroup): latency-bound, more waves
-#define MRC_SMR_WAVES_PER_EU_SHORT 8
+// short blocks (two waves, ~5 KB of LDS per workgroup) are latency-bound: more waves.  Measured per 114 688 short units: 4 waves
+// per SIMD 0.714 ms, 5: 0.657, 6: 0.627, 8: 0.612 -- but at 8 (64 registers) 16 registers spill and the scratch traffic is
+// 1 GB per step of configs[3] (PMC WRITE_SIZE); 6 (77 registers) spills none.
+#ifndef MRC_SMR_WAVES_PER_EU_SHORT
+#define MRC_SMR_WAVES_PER_EU_SHORT 6
 #endif
 #if MRC_SMR_WAVES_PER_EU > 0
 #define MRC_SMR_OCC __attribute__((amdgpu_waves_per_eu(DIM == 128 ? MRC_SMR_WAVES_PER_EU_SHORT : MRC_SMR_WAVES_PER_EU, \
