@@ -81,7 +81,7 @@ def coded_line_fraction(np, out, bands):
 
 
 KERNEL_NAMES = ["mdct", "smr", "band_stats", "bitalloc", "quantize"]
-KERNEL_LABEL = {"mdct": "mdct_long_kernel", "smr": "smr_kernel", "band_stats": "ms_switch_kernel",
+KERNEL_LABEL = {"mdct": "mdct_long_kernel", "smr": "smr_kernel", "band_stats": "ms_switch_direct_kernel",
                 "bitalloc": "bitalloc_kernel", "quantize": "quantize_kernel"}
 
 
@@ -532,7 +532,7 @@ def main():
             abk = algorithmic_bytes(False, True, True, a, b, nb, coded_line_frac=coded_line_fraction(np, oo, bands_ab))
             label = dict(KERNEL_LABEL)
             if (a, b) != (HOP, HOP):
-                label["mdct"] = "mdct_kernel"
+                label["mdct"] = "mdct_wave_kernel"
             rr = kernel_report(list(zip(KERNEL_NAMES, km)), abk, o.numel(), {}, label)   # (PMC traffic: per config, below)
             for r in rr:
                 r["shape"] = "%dx%d" % (a, b)
