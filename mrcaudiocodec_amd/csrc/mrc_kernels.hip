@@ -456,76 +456,15 @@ __global__ void stereo_masking_kernel(int64_t n, const double* __restrict__ mid,
 // exactly as np.sum rounds them (pairwise summation, restated as the static tree of mrc::ms_plan).  A LEAF is a run
 // of <= 128 lines: eight lanes hold NumPy's eight strided accumulators r[0..7], combine them in its fixed order
 // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) with three in-register exchanges and add the < 8 trailing elements one by one;
-// runs of fewer than 8 lines are plain left-to-right sums.  Eight leaves are in flight per wave; one lane then adds the
-// few internal nodes (bands of more than 128 lines) in tree order.
-// STAGED: the block's L and R lines (nLines each, a multiple of 2, 16-byte aligned) are first copied into LDS by 16-byte
-// coalesced loads -- a leaf's eight lanes read eight CONSECUTIVE doubles per step, so straight from global memory a wave's
-// load touches eight separate 64-byte segments (2.8 TB/s measured); from LDS the same pattern is free.
-constexpr int kMsStageLines = 1024;
-template <bool STAGED>
-__global__ __launch_bounds__(kWave) void ms_switch_kernel(int nBands, int nLeaves, int nInternal, int nLines,
-                                                          const int* __restrict__ plan, const double* __restrict__ L,
-                                                          const double* __restrict__ R, int64_t blockStride,
-                                                          int* __restrict__ out) {
-    __shared__ double sumD[64], sumS[64];
-    __shared__ __attribute__((aligned(16))) double stage[STAGED ? 2 * kMsStageLines : 2];
-    const int lane = threadIdx.x, g = lane >> 3, j = lane & 7;
-    const int64_t blk = blockIdx.x;
-    const double* l = L + blk * blockStride;
-    const double* r = R + blk * blockStride;
-    if (STAGED) {
-        for (int k = 2 * lane; k < nLines; k += 2 * kWave) {
-            *reinterpret_cast<double2*>(stage + k) = *reinterpret_cast<const double2*>(l + k);
-            *reinterpret_cast<double2*>(stage + kMsStageLines + k) = *reinterpret_cast<const double2*>(r + k);
-        }
-        __syncthreads();
-        l = stage;
-        r = stage + kMsStageLines;
-    }
-    auto dOf = [&](int k) { const double a = l[k], b = r[k]; return fabs(a * a - b * b); };
-    auto sOf = [&](int k) { const double a = l[k], b = r[k]; return fabs(a * a + b * b); };
-    for (int t0 = 0; t0 < nLeaves; t0 += 8) {
-        const int t = t0 + g;
-        const bool have = t < nLeaves;
-        const int lo = have ? plan[2 * t] : 0, n = have ? plan[2 * t + 1] : 8;
-        double d, sgm;
-        // the exchanges below need every lane; lanes without a leaf run a dummy 8-element leaf at line 0
-        if (n < 8) {
-            d = 0.; sgm = 0.;
-            for (int i = 0; i < n; ++i) { d += dOf(lo + i); sgm += sOf(lo + i); }
-            // (keep the DPP steps convergent for the whole wave)
-            (void)dpp_move<0xB1>(d);
-        } else {
-            d = dOf(lo + j); sgm = sOf(lo + j);
-            const int body = n - (n % 8);
-            for (int i = 8; i < body; i += 8) { d += dOf(lo + i + j); sgm += sOf(lo + i + j); }
-            d += dpp_move<0xB1>(d);   sgm += dpp_move<0xB1>(sgm);     // r0+r1, r2+r3, ...   (quad_perm [1,0,3,2])
-            d += dpp_move<0x4E>(d);   sgm += dpp_move<0x4E>(sgm);     // (r0+r1)+(r2+r3), ... (quad_perm [2,3,0,1])
-            d += dpp_move<0x141>(d);  sgm += dpp_move<0x141>(sgm);    // + the other quad     (row_half_mirror)
-            for (int i = body; i < n; ++i) { d += dOf(lo + i); sgm += sOf(lo + i); }
-        }
-        if (have && j == 0) { sumD[t] = d; sumS[t] = sgm; }
-    }
-    __syncthreads();
-    if (lane == 0) {
-        const int* inner = plan + 2 * nLeaves;
-        for (int q = 0; q < nInternal; ++q) {
-            sumD[nLeaves + q] = sumD[inner[2 * q]] + sumD[inner[2 * q + 1]];
-            sumS[nLeaves + q] = sumS[inner[2 * q]] + sumS[inner[2 * q + 1]];
-        }
-    }
-    __syncthreads();
-    if (lane < nBands) {
-        const int root = plan[2 * nLeaves + 2 * nInternal + lane];
-        out[blk * nBands + lane] = sumD[root] < 0.8 * sumS[root] ? 1 : 0;
-    }
-}
-
-// The same sums with NO staging and every load of a leaf round in flight at once: a wavefront per block, four blocks per
-// workgroup.  The staged form above holds 16.5 KB of LDS per wavefront -- nine wavefronts per CU, each walking its leaves
-// step by step (load -> add -> load ...): latency-bound at 38 % of the HBM rate.  Here a lane's <= 16 strided elements and
-// <= 7 trailing elements of a leaf are requested together (predicated loads, no requests from idle lanes), the sums run over
-// registers in NumPy's order, and the only LDS is the 64 node sums per wave.
+// runs of fewer than 8 lines are plain left-to-right sums.  Eight leaves are in flight per wave (a "round"; the plan lists
+// the leaves longest first so that the rounds are even); the few internal nodes (bands of more than 128 lines) follow in
+// tree order.
+// No staging, and every load of a round in flight at once.  Earlier forms (a leaf walked step by step from global memory;
+// the block staged through 16.5 KB of LDS per wave) all took 0.31-0.35 ms per 65 536 long blocks whatever their memory
+// pattern: the kernel was bound by its chain of dependent round trips at 9-16 waves per CU.  Here a lane's <= 16 strided
+// elements of a leaf are requested together (predicated loads: idle lanes make no requests), the < 8 trailing lines sit
+// one per lane and reach lane 0 through DPP row shifts, the plan's entries are requested before anything else, the sums
+// run over registers in NumPy's order, and the only LDS is the 64 node sums per wave: 0.25 ms.
 constexpr int kMsWaves = 4;
 constexpr int kMsMaxSteps = 16, kMsRounds = 8;          // leaf <= 128 lines; <= 64 leaves, eight per round
 template <int CTRL> __device__ __forceinline__ double dpp_from(double v) {           // lane i reads lane i + (CTRL - 0x100) of its row
@@ -730,22 +669,10 @@ hipError_t launch_stereo_masking(int64_t n, const double* mid, const double* sid
 hipError_t launch_ms_switch(int64_t nBlocks, int nBands, int nLeaves, int nInternal, const int* plan, const double* L,
                             const double* R, int64_t blockStride, int nLines, int* out, hipStream_t st) {
     if (nBlocks <= 0) return hipSuccess;
-    const bool staged = nLines > 0 && nLines <= kMsStageLines && !(nLines & 1) && !(blockStride & 1) &&
-                        !((reinterpret_cast<uintptr_t>(L) | reinterpret_cast<uintptr_t>(R)) & 15);
-#ifndef MRC_MS_DIRECT                            // 1: ms_switch_direct_kernel (no staging, a leaf round's loads in flight at once)
-#define MRC_MS_DIRECT 1
-#endif
-    if (MRC_MS_DIRECT && nLeaves <= 8 * kMsRounds) {
-        hipLaunchKernelGGL(ms_switch_direct_kernel, dim3((unsigned)((nBlocks + kMsWaves - 1) / kMsWaves)), dim3(kWave * kMsWaves),
-                           0, st, nBlocks, nBands, nLeaves, nInternal, plan, L, R, blockStride, out);
-        return hipGetLastError();
-    }
-    if (staged)
-        hipLaunchKernelGGL(ms_switch_kernel<true>, dim3((unsigned)nBlocks), dim3(kWave), 0, st, nBands, nLeaves, nInternal,
-                           nLines, plan, L, R, blockStride, out);
-    else
-        hipLaunchKernelGGL(ms_switch_kernel<false>, dim3((unsigned)nBlocks), dim3(kWave), 0, st, nBands, nLeaves, nInternal,
-                           nLines, plan, L, R, blockStride, out);
+    (void)nLines;
+    if (nLeaves > 8 * kMsRounds) return hipErrorInvalidValue;      // (build_shape admits at most 64 nodes)
+    hipLaunchKernelGGL(ms_switch_direct_kernel, dim3((unsigned)((nBlocks + kMsWaves - 1) / kMsWaves)), dim3(kWave * kMsWaves),
+                       0, st, nBlocks, nBands, nLeaves, nInternal, plan, L, R, blockStride, out);
     return hipGetLastError();
 }
 
