@@ -17,6 +17,31 @@ from oracle import codec as ocodec, fast
 pytestmark = pytest.mark.gpu
 
 MDCT_RTOL = 1e-12
+@pytest.mark.parametrize("ab", [(1024, 1024), (128, 128), (1024, 128)])
+def test_encode_joint_all_bands_on_one_side_of_the_switch(h, ab):
+    # smr_kernel ends a unit none of whose bands the M/S switch selects before its first load (its SMRs and band peaks have
+    # no reader: ms_stereo.py:70-81).  Frames whose bands ALL take M/S (identical and nearly identical channels), frames
+    # whose bands all stay L/R (one silent channel) and mixed frames (unrelated, partly related), in ONE batch so that skipped and
+    # computed units sit side by side -- every integer against the oracle.
+    from mrcaudiocodec_amd import synth
+    a, b = ab
+    n = 96
+    g1, g2 = synth.c2_noise(n + 2, seed=5), synth.c2_noise(n + 2, seed=6)
+    bl = np.stack([g1[i * b:i * b + a + b] for i in range(n)])
+    br_other = np.stack([g2[i * b:i * b + a + b] for i in range(n)])
+    br = br_other.copy()
+    kind = np.arange(n) % 5
+    br[kind == 0] = bl[kind == 0]                                   # identical: S = 0, every band M/S
+    br[kind == 1] = 0.95 * bl[kind == 1] + 0.05 * br_other[kind == 1]   # nearly identical
+    br[kind == 3] = 0.0                                             # a silent channel: every band L/R
+    br[kind == 4] = 0.8 * bl[kind == 4] + 0.2 * br_other[kind == 4]     # mixed (kind 2: unrelated channels of equal level)
+    got = h.encode_joint(bl, br, a, b)
+    ref = fast.encode_joint_batch(bl, br, a, b)
+    _assert_int_parity(got, ref, joint=True)
+    sw = np.asarray(ref["ms_switch"])[:, :len(h.bands(a, b))]
+    assert sw.all(axis=1).sum() >= n // 8 and (~sw.any(axis=1)).sum() >= n // 8      # both whole-unit cases occur
+
+
 DB_ATOL = 1e-9
 SHAPES = [(1024, 1024), (128, 128), (1024, 128), (128, 1024)]
 
