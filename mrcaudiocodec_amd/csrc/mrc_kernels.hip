@@ -155,9 +155,36 @@ __device__ __forceinline__ double2* wave_fft(double2* A, double2* B, const doubl
     return A;
 }
 
+// Four per-lane partial maxima (one per unit of a group) -> every lane of row r (lanes 16 r .. 16 r + 15) ends with the
+// wave-wide maximum of value r: two rounds of permlane swaps fold the four registers into one whose rows belong to the four
+// values, then one reduction inside the rows -- a quarter of four separate wave reductions.
+__device__ __forceinline__ double wave_max4(double p0, double p1, double p2, double p3) {
+    auto swap = [](double a, double b, bool half, double* x, double* y) {
+        const unsigned al = (unsigned)__double2loint(a), ah = (unsigned)__double2hiint(a);
+        const unsigned bl = (unsigned)__double2loint(b), bh = (unsigned)__double2hiint(b);
+        const uint2v l = half ? __builtin_amdgcn_permlane32_swap(al, bl, false, false)
+                              : __builtin_amdgcn_permlane16_swap(al, bl, false, false);
+        const uint2v h = half ? __builtin_amdgcn_permlane32_swap(ah, bh, false, false)
+                              : __builtin_amdgcn_permlane16_swap(ah, bh, false, false);
+        *x = __hiloint2double((int)h.x, (int)l.x);
+        *y = __hiloint2double((int)h.y, (int)l.y);
+    };
+    double x, y;
+    swap(p0, p2, true, &x, &y);                         // x = {p0 lower half, p2 lower half}, y = {p0 upper, p2 upper}
+    const double m02 = fmax(x, y);                      // lanes 0-31: value 0 over both halves; lanes 32-63: value 2
+    swap(p1, p3, true, &x, &y);
+    const double m13 = fmax(x, y);                      // lanes 0-31: value 1; lanes 32-63: value 3
+    swap(m02, m13, false, &x, &y);                      // x = {m02 row 0, m13 row 0, m02 row 2, m13 row 2}, y = the odd rows
+    double q = fmax(x, y);                              // row r: value r
+    q = fmax(q, dpp_move<0xB1>(q));
+    q = fmax(q, dpp_move<0x4E>(q));
+    q = fmax(q, dpp_move<0x141>(q));
+    return fmax(q, dpp_move<0x128>(q));
+}
+
 constexpr int kMdctWaves = 4;                           // waves per workgroup, each with its own groups of units
 constexpr int kMdctMaxRun = 8;                          // groups per wave, at most
-template <class SampleT, int N, int U, int NSIG>
+template <class SampleT, int N, int U, int NSIG, bool SHIFT0>
 __global__ __launch_bounds__(kWave * kMdctWaves, 2) void mdct_wave_kernel(
     DevShape S, int64_t nUnits, int run, const SampleT* __restrict__ chL, const SampleT* __restrict__ chR, int64_t stride,
     const int64_t* __restrict__ offsets, double* __restrict__ lines, int* __restrict__ oscale) {
@@ -179,18 +206,20 @@ __global__ __launch_bounds__(kWave * kMdctWaves, 2) void mdct_wave_kernel(
     __shared__ long long sOff[kMdctWaves][kMdctMaxRun * U];                          // sample offset of every unit of a wave's run
     for (int t = threadIdx.x; t < Q; t += kWave * kMdctWaves) wl[t] = S.wQ[t];
     // lane constants: window value of every sample slot and where the sample goes after the signed circular shift by
-    // (b-a)/4 (see mdct_kernel; bit 31: negated); pre- and post-twiddle of every point slot
+    // (b-a)/4 (see mdct_kernel; bit 31: negated; SHIFT0: a = b, no shift); pre- and post-twiddle of every point slot
     double wv[kSlots];
-    unsigned dst[kSlots];
+    unsigned dst[SHIFT0 ? 1 : kSlots];
 #pragma unroll
     for (int c = 0; c < kSlots; ++c) {
         const int n = lane + kWave * (c % kSlotsPerUnit);
         wv[c] = S.win[n];
-        int m = n + S.shift;
-        unsigned neg = 0;
-        if (m < 0) { m += N; neg = 1u << 31; }
-        else if (m >= N) { m -= N; neg = 1u << 31; }
-        dst[c] = (unsigned)(m + (c / kSlotsPerUnit) * N) | neg;
+        if (!SHIFT0) {
+            int m = n + S.shift;
+            unsigned neg = 0;
+            if (m < 0) { m += N; neg = 1u << 31; }
+            else if (m >= N) { m -= N; neg = 1u << 31; }
+            dst[SHIFT0 ? 0 : c] = (unsigned)(m + (c / kSlotsPerUnit) * N) | neg;
+        }
     }
     double2 preR[kPoints], postR[kPoints];
 #pragma unroll
@@ -238,7 +267,8 @@ __global__ __launch_bounds__(kWave * kMdctWaves, 2) void mdct_wave_kernel(
                 v = sig == 2 ? (l + r) / 2.0 : (l - r) / 2.0;
             }
             const double x = v * wv[c];
-            y[dst[c] & 0x7fffffffu] = (dst[c] >> 31) ? -x : x;
+            if (SHIFT0) y[(c / kSlotsPerUnit) * N + lane + kWave * (c % kSlotsPerUnit)] = x;
+            else y[dst[SHIFT0 ? 0 : c] & 0x7fffffffu] = (dst[SHIFT0 ? 0 : c] >> 31) ? -x : x;
         }
         if (it + 1 < run && u0 + U < nUnits) request(it + 1);          // in flight while this group is transformed
         wave_sync();
@@ -272,7 +302,20 @@ __global__ __launch_bounds__(kWave * kMdctWaves, 2) void mdct_wave_kernel(
             }
         }
         wave_sync();
-        // ---- E. lines out (512 contiguous bytes per store), overall scale per unit (codecThem.py:321-322)
+        // ---- E. lines out (512 / 1024 contiguous bytes per store), overall scale per unit (codecThem.py:321-322)
+        if (U == 4 && M == 2 * kWave) {
+            // four units of 128 lines: a 16-byte store per lane and unit, the four peaks reduced together
+            double pk[4];
+#pragma unroll
+            for (int uu = 0; uu < 4; ++uu) {
+                const double2 x = *reinterpret_cast<const double2*>(stage + uu * M + 2 * lane);
+                if (u0 + uu < nUnits) *reinterpret_cast<double2*>(lines + (u0 + uu) * M + 2 * lane) = x;
+                pk[uu] = fmax(fabs(x.x), fabs(x.y));
+            }
+            const double peak = wave_max4(pk[0], pk[1], pk[2], pk[3]);
+            const int r = lane >> 4;
+            if ((lane & 15) == 0 && u0 + r < nUnits) oscale[u0 + r] = scale_factor_dev(peak, S.nScaleBits, 5);
+        } else
 #pragma unroll
         for (int uu = 0; uu < U; ++uu) {
             const int64_t unit = u0 + uu;
@@ -558,7 +601,7 @@ hipError_t launch_mdct(const DevShape& S, int64_t nFrames, const void* chL, cons
     // the other shapes of the reference's block switching (short 128 + 128: four units per wavefront at a time; transitions
     // 1024 + 128 and 128 + 1024: one), windowed: mdct_wave_kernel.  The run length trades the once-per-workgroup constants
     // against the number of workgroups.
-    if (applyWindow && (S.N == 256 || S.N == 1152)) {
+    if (applyWindow && !(reinterpret_cast<uintptr_t>(lines) & 15) && ((S.N == 256 && S.shift == 0) || S.N == 1152)) {
         const int64_t nUnits = nFrames * nsig;
         const int U = S.N == 256 ? 4 : 1;
         const int64_t groups = (nUnits + U - 1) / U;
@@ -566,7 +609,7 @@ hipError_t launch_mdct(const DevShape& S, int64_t nFrames, const void* chL, cons
         const unsigned grid = (unsigned)((groups + (int64_t)kMdctWaves * run - 1) / ((int64_t)kMdctWaves * run));
         const size_t ldsW = (size_t)(kMdctWaves * (U * S.N + 2 * U * S.Q) + 2 * S.Q) * sizeof(double);
 #define MRC_MDCT_WAVE(TY, NN, UU, NS)                                                                                  \
-    hipLaunchKernelGGL((mdct_wave_kernel<TY, NN, UU, NS>), dim3(grid), dim3(kWave * kMdctWaves), ldsW, st, S, nUnits, run, \
+    hipLaunchKernelGGL((mdct_wave_kernel<TY, NN, UU, NS, NN == 256>), dim3(grid), dim3(kWave * kMdctWaves), ldsW, st, S, nUnits, run, \
                        (const TY*)chL, (const TY*)chR, stride, offsets, lines, oscale)
 #define MRC_MDCT_WAVE_T(TY)                                                                                            \
     do {                                                                                                               \
