@@ -214,6 +214,29 @@ def test_encode_short_and_transition(h, ab):
     _assert_int_parity(h.encode_joint(blocks, mixed, a, b), fast.encode_joint_batch(blocks, mixed, a, b), joint=True)
 
 
+@pytest.mark.parametrize("ab", [(128, 128), (1024, 128), (128, 1024)])
+def test_short_and_transition_ragged_counts(h, ab):
+    # mdct_wave_kernel takes the short blocks four at a time and walks runs of groups per wave: counts that end inside a
+    # group, inside a run and inside a workgroup (1, 2, 3, 5, 13 blocks; joint blocks: units = 4 x blocks), and one count
+    # large enough for runs of several groups per wave
+    a, b = ab
+    n_big = 36003 if a + b == 256 else 9001             # > 8192 groups: every wave walks a run of two or more groups
+    big = _noise_blocks(a, b, n_big, seed=7, sigma=0.2)
+    right = _noise_blocks(a, b, 13, seed=8, sigma=0.2)
+    for n in (1, 2, 3, 5, 13):
+        _assert_int_parity(h.encode_mono(big[:n], a, b), fast.encode_mono_batch(big[:n], a, b))
+        _assert_int_parity(h.encode_joint(big[:n], right[:n], a, b), fast.encode_joint_batch(big[:n], right[:n], a, b), joint=True)
+    got = h.encode_mono(big, a, b)
+    ref = fast.encode_mono_batch(big[-40:], a, b)
+    for k in _int_keys(False):
+        assert np.array_equal(np.asarray(got[k])[-40:], np.asarray(ref[k])), k
+    # ... and the whole large batch against itself in pieces small enough for one group per wave
+    for lo in range(0, n_big, 4000):
+        part = h.encode_mono(big[lo:lo + 4000], a, b)
+        for k in _int_keys(False):
+            assert np.array_equal(np.asarray(got[k])[lo:lo + 4000], np.asarray(part[k])), (k, lo)
+
+
 def test_block_switching_stream(h):
     from mrcaudiocodec_amd import synth
     x, shapes = synth.c4_transients(25)
