@@ -1107,6 +1107,13 @@ int mrc_huffman_gain(mrc_handle* h, int64_t n, int a, int b, int n_streams, cons
     return MRC_OK;
 }
 
+// every section behind the first has b0 == 1.0 exactly (scipy's tf2sos / zpk2sos put the gain into the first section)
+static bool sos_unit_b0(const double* sos, int n_sections) {
+    for (int s = 1; s < n_sections; ++s)
+        if (sos[6 * s] != 1.0) return false;
+    return true;
+}
+
 int mrc_transient_peaks_ex(mrc_handle* h, int64_t n_hops, int n_channels, int n_sections, const double* sos,
                            const void* streams, int sample_format, double* peaks) {
     if (!h || !sos || !streams || !peaks || n_hops < 0 || n_channels < 1 || n_sections < 1 || n_sections > 16 ||
@@ -1124,7 +1131,7 @@ int mrc_transient_peaks_ex(mrc_handle* h, int64_t n_hops, int n_channels, int n_
     const size_t outBytes = (size_t)n_hops * n_channels * (hop / nShort + 1) * sizeof(double);
     MRC_HIP(h, h->outG.reserve(outBytes));
     MRC_HIP(h, launch_transient_peaks(n_hops, n_channels, hop, nShort, n_sections, h->inAux3.as<double>(),
-                                      h->inL.p, sample_format, chStride, h->outG.as<double>(), h->stream));
+                                      sos_unit_b0(sos, n_sections), h->inL.p, sample_format, chStride, h->outG.as<double>(), h->stream));
     MRC_TRY(s.down(peaks, h->outG, outBytes));
     MRC_HIP(h, hipStreamSynchronize(h->stream));
     return MRC_OK;
@@ -1150,8 +1157,8 @@ int mrc_dev_transient_peaks(mrc_handle* h, int64_t n_hops, int n_channels, int n
     MRC_HIP(h, h->inAux3.reserve((size_t)n_sections * 6 * sizeof(double)));
     MRC_HIP(h, hipMemcpyAsync(h->inAux3.p, sos, (size_t)n_sections * 6 * sizeof(double), hipMemcpyHostToDevice, st));
     MRC_HIP(h, hipStreamSynchronize(st));                    // `sos` may be a temporary of the caller
-    MRC_HIP(h, launch_transient_peaks(n_hops, n_channels, hop, nShort, n_sections, h->inAux3.as<double>(), streams,
-                                      sample_format, channel_stride, peaks, st));
+    MRC_HIP(h, launch_transient_peaks(n_hops, n_channels, hop, nShort, n_sections, h->inAux3.as<double>(),
+                                      sos_unit_b0(sos, n_sections), streams, sample_format, channel_stride, peaks, st));
     return MRC_OK;
 }
 

@@ -185,7 +185,7 @@ hipError_t launch_scale_factor(int64_t n, int nScaleBits, const double* v, const
                                hipStream_t st);
 hipError_t launch_mantissa(int64_t n, int nScaleBits, const double* x, const int* scale, const int* nMantBits,
                            int* out, hipStream_t st);
-hipError_t launch_transient_peaks(int64_t nHops, int nCh, int hop, int nShort, int nSec, const double* sos,
+hipError_t launch_transient_peaks(int64_t nHops, int nCh, int hop, int nShort, int nSec, const double* sos, bool unitB0,
                                   const void* streams, int fmt, int64_t chStride, double* peaks, hipStream_t st);
 hipError_t launch_stereo_masking(int64_t n, const double* mid, const double* side, const double* z, double* outMid,
                                  double* outSide, hipStream_t st);

@@ -397,7 +397,9 @@ constexpr int kMaxSections = 16;
 // VEC: every hop starts on a 16-byte boundary: the samples come eight (int16) / two (double) per load, and the next group is
 // requested before the current one is filtered.
 // NSEC == 0: any section count up to kMaxSections, coefficients as the compiler pleases.
-template <class SampleT, int NSEC, bool VEC>
+// UNIT: every section but the first has b0 == 1.0 exactly (what tf2sos / zpk2sos produce: the gain sits in the first
+// section): their `b0 * x` is x -- the same value, one multiplication per section and sample less.
+template <class SampleT, int NSEC, bool VEC, bool UNIT>
 __global__ __launch_bounds__(kWave) void transient_peaks_kernel(int64_t nHops, int nCh, int hop, int nShort, int nSecArg,
                                                                  const double* __restrict__ sos,
                                                                  const SampleT* __restrict__ streams, int64_t chStride,
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(kWave) void transient_peaks_kernel(int64_t nHops, i
                 const double c0 = NSEC ? b0[s] : sos[6 * s], c1 = NSEC ? b1[s] : sos[6 * s + 1];
                 const double c2 = NSEC ? b2[s] : sos[6 * s + 2];
                 const double d1 = NSEC ? a1[s] : sos[6 * s + 4], d2 = NSEC ? a2[s] : sos[6 * s + 5];
-                const double y = c0 * cur + z0[s];
+                const double y = (UNIT && s > 0) ? cur + z0[s] : c0 * cur + z0[s];
                 z0[s] = (c1 * cur - d1 * y) + z1[s];
                 z1[s] = c2 * cur - d2 * y;
                 cur = y;
@@ -683,7 +685,7 @@ hipError_t launch_mantissa(int64_t n, int nScaleBits, const double* x, const int
     return hipGetLastError();
 }
 
-hipError_t launch_transient_peaks(int64_t nHops, int nCh, int hop, int nShort, int nSec, const double* sos,
+hipError_t launch_transient_peaks(int64_t nHops, int nCh, int hop, int nShort, int nSec, const double* sos, bool unitB0,
                                   const void* streams, int fmt, int64_t chStride, double* peaks, hipStream_t st) {
     const int64_t n = nHops * nCh;
     if (n <= 0) return hipSuccess;
@@ -691,12 +693,14 @@ hipError_t launch_transient_peaks(int64_t nHops, int nCh, int hop, int nShort, i
     const bool vec = !(reinterpret_cast<uintptr_t>(streams) & 15) && !((chStride * sz) & 15) && !((hop * sz) & 15) &&
                      !((nShort * sz) & 15) && nShort > 0 && hop % nShort == 0;
     const dim3 grid((unsigned)((n + kWave - 1) / kWave)), block(kWave);
-#define MRC_TP_LAUNCH(TY, NS, VC)                                                                                     \
-    hipLaunchKernelGGL((transient_peaks_kernel<TY, NS, VC>), grid, block, 0, st, nHops, nCh, hop, nShort, nSec, sos,   \
+#define MRC_TP_LAUNCH(TY, NS, VC, UN)                                                                                 \
+    hipLaunchKernelGGL((transient_peaks_kernel<TY, NS, VC, UN>), grid, block, 0, st, nHops, nCh, hop, nShort, nSec, sos,  \
                        (const TY*)streams, chStride, peaks)
-    // the reference's filter (cheby2 of order 20: ten sections) on aligned hops takes the specialised form
-    if (fmt == kSampleI16) { if (nSec == 10 && vec) MRC_TP_LAUNCH(short, 10, true); else MRC_TP_LAUNCH(short, 0, false); }
-    else { if (nSec == 10 && vec) MRC_TP_LAUNCH(double, 10, true); else MRC_TP_LAUNCH(double, 0, false); }
+    // the reference's filter (cheby2 of order 20 through tf2sos: ten sections, unit b0 behind the first) on aligned hops
+    // takes the specialised form
+    const bool special = nSec == 10 && vec && unitB0;
+    if (fmt == kSampleI16) { if (special) MRC_TP_LAUNCH(short, 10, true, true); else MRC_TP_LAUNCH(short, 0, false, false); }
+    else { if (special) MRC_TP_LAUNCH(double, 10, true, true); else MRC_TP_LAUNCH(double, 0, false, false); }
 #undef MRC_TP_LAUNCH
     return hipGetLastError();
 }
