@@ -357,7 +357,9 @@ int mrc_dev_pack_status(mrc_handle* h, int64_t* total_bytes, void* stream);
  *     is the complete `.pac` file of stream s.
  *   out [out_cap]: size it with mrc_chain_out_bound, or less and retry on MRC_ERR_NOMEM (total_bytes then holds the
  *     size needed).  item_byte_offset (NULL or [n_items + 1], n_items = blocks + 2 n_streams with_flush): where every
- *     block's chunks start.  reservoir_out (NULL or [n_streams]): codingParams.bitReservoir after the last block.
+ *     block's chunks start (asked for, the position of every chunk is read back from the device: 8 bytes per chunk; with
+ *     NULL only the stream starts come back).  reservoir_out (NULL or [n_streams]): codingParams.bitReservoir after the
+ *     last block.
  *     reservoir_trace (NULL or [n_items]): ... after every block (tests).
  * mrc_dev_encode_chained_pac: the same with pcm_left / pcm_right / out in DEVICE memory (all other pointers host);
  * it synchronises `stream` before it returns (the byte offsets come back).  mrc_get_chain_ms: device time of the last
