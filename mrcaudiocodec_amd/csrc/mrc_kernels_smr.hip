@@ -945,7 +945,9 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         // four independent scans, dealt to the workgroup's waves (4 waves: one each; 2 waves: two each)
         for (int task = wave; task < 4; task += NT / kWave) {
         if (task == 0) {
-            constexpr int kSeg = 8;                     // kWave * kSeg = 512 >= max number of peaks (N/4)
+            // kWave * kSeg >= the block's maximum number of peaks + 1: 512 >= N/4 in general; a block of DIM lines has at
+            // most (DIM - 101) / 2 (13 for the short block: one per lane; 237 for the transition blocks: four)
+            constexpr int kSeg = DIM == 128 ? 1 : DIM == 576 ? 4 : 8;
             double loc[kSeg];
             double run = 0.0;
             const int seg = kWave - 1 - lane;           // lanes take the segments in REVERSE order, so that the suffix
@@ -973,7 +975,7 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
             // pi[m] = I_0 + ... + I_{m-1} in double-double: the in-band sum of a line is a DIFFERENCE of two
             // prefix sums, and with ~106 bits the difference is exact to far below one ulp of the result even
             // when a loud masker sits in the prefix (dynamic range of I within a frame < 2^50)
-            constexpr int kSeg = 8;
+            constexpr int kSeg = DIM == 128 ? 1 : DIM == 576 ? 4 : 8;
             double hi = 0.0, lo = 0.0, locH[kSeg], locL[kSeg];
 #pragma unroll
             for (int i = 0; i < kSeg; ++i) {
