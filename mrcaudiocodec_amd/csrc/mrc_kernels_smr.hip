@@ -24,6 +24,8 @@
 //                 within 1e-10 dB (tests/test_gpu_parity.py::test_spread_modes_agree).
 // DESIGN.md section 4 has the derivations, the error bounds and the measured instruction counts.
 #include "mrc_device.hpp"
+
+#include <algorithm>
 #include "mrc_log10.hpp"
 
 namespace mrc {
@@ -41,6 +43,13 @@ __device__ __forceinline__ unsigned long long order_key(double v) {
 __device__ __forceinline__ double order_value(unsigned long long k) {
     unsigned long long b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
     return __longlong_as_double((long long)b);
+}
+// LDS traffic between lanes of ONE wave (smr_short_kernel): order the wave's own DS operations, keep the compiler from
+// moving LDS accesses across this point
+__device__ __forceinline__ void wave_sync_lds() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 // far-field expansion (see the sweep): highest order, fewest maskers worth it, and for each supported order J the
 // largest |x| with |x|^(J+1)/(J+1)! e^|x| below 1e-15 (x = slope spread * half the Bark span of a group of lines)
@@ -1336,6 +1345,185 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
                                                     nullptr, bandPeakArg, msSwitch, SmrLds{0, 0, 0});
 }
 
+// ------------------------------------------------------------------------------------------------
+// smr_short_kernel -- the same quantities as smr_kernel for the reference's SHORT block (a = b = 128: 128 lines, 28 searched
+// bins, at most 13 maskers), one WAVEFRONT per unit and no workgroup barrier.  smr_kernel's machinery -- masker-side
+// searches, histograms and scans, prefix / suffix sums, the sorted sweep with its far field -- pays for itself with hundreds
+// of maskers; with thirteen it is overhead (1 800 VALU instructions per unit in two waves, 61 % VALU busy: `profiles/
+// r03_shapes_sq_counters.txt`).  Here a lane owns two lines and adds the maskers one by one, in the reference's own order
+// (psychoac.py:166-168): I_m inside +-1/2 Bark, I_m 2^(slope x (|dz| - 1/2)) outside, with the level-dependent slope above the
+// masker and -27 dB/Bark below it -- one table-driven 2^x per (masker, line).  Maskers, SPL conversions, the ratio form of the
+// band maximum and the floor handling are smr_kernel's (same helpers).  A wave walks `run` consecutive units; the tables
+// (FFT twiddle quadrant, 2^x, log10) are staged once per workgroup, Hann values and per-line constants live in registers.
+// ------------------------------------------------------------------------------------------------
+// One masker's table entry {I, z, upper slope in 1/64 bit per Bark} from the sum of its three bins and the numerator of its
+// centre frequency.  OUT OF LINE on purpose: it runs once per unit on at most 13 lanes, and inlined its ~60 polynomial
+// constants would sit in registers across the whole unit loop (145 registers instead of ~100: a wave per SIMD less).
+__device__ __attribute__((noinline)) void short_masker(double s3, double fnum, const double* logTab, double* e) {
+    const double level = spl_db_tab(s3, logTab);                              // psychoac.py:164
+    const double fm = fnum * recip_nr(s3);                                    // psychoac.py:165
+    const double q = fm * (1. / 7500.);                                       // psychoac.py:27-29
+    const double zm = 13 * atan_pos((0.76 * fm) * 1e-3) + 3.5 * atan_pos(q * q);
+    const double lvl15 = level - 15.0;                                        // psychoac.py:42-43 (tonal drop)
+    const double boost = 0.37 * fmax(level - 40, 0.0);                        // psychoac.py:76
+    const double xe = (lvl15 - 96) * 0.1;                                     // psychoac.py:14-18
+    const double eh = xe * kLog2Of10;
+    e[0] = exp2_dd(eh, fma(xe, kLog2Of10, -eh) + xe * kLog2Of10Lo);
+    e[1] = zm;
+    e[2] = (((-27 + boost) * 0.1) * kLog2Of10) * (double)kExpTab;
+}
+
+// ... and the conversion of a band's maximal ratio (once per band and unit; out of line for the same reason)
+__device__ __attribute__((noinline)) double short_band_db(double q, int scale, const double* logTab) {
+    return 10 * log10_tab32(q, logTab) - 6. * scale;
+}
+
+constexpr int kShortWaves = 4;
+constexpr int kShortWaveLds = 256 + 256 + 32 + 64 + 96;        // doubles per wave: A | B (FFT) | xi | masker table | three key arrays
+constexpr int kShortSharedLds = 64 + kExpTab + kLogTabEntries * 4;   // twiddle quadrant | 2^(j/64) | log10 table
+template <class SampleT, int MODE>
+#ifndef MRC_SMR_SHORT_OCC
+#define MRC_SMR_SHORT_OCC 4
+#endif
+__global__ __launch_bounds__(kWave * kShortWaves) __attribute__((amdgpu_waves_per_eu(MRC_SMR_SHORT_OCC, MRC_SMR_SHORT_OCC))) void smr_short_kernel(
+    DevShape S, int64_t nUnits, int run, const SampleT* __restrict__ chL, const SampleT* __restrict__ chR, int64_t stride,
+    const int64_t* __restrict__ offsets, const double* __restrict__ lines, const int* __restrict__ oscale,
+    double* __restrict__ smr, double* __restrict__ bandPeak, const int* __restrict__ msSwitch) {
+    constexpr int H = 128, M = 128, last = 28;
+    constexpr int nsig = MODE == 1 ? 1 : 4;
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    double* ws = smem + wave * kShortWaveLds;
+    double2* A = reinterpret_cast<double2*>(ws);
+    double2* B = A + H;
+    double* xi = ws + 4 * H;
+    double* mt = xi + 32;                               // [<= 13][4]: I, z, upper slope (1/64 bit per Bark), -
+    unsigned long long* ratioKey = reinterpret_cast<unsigned long long*>(mt + 64);
+    unsigned long long* bandKey = ratioKey + 32;
+    unsigned long long* peakKey = bandKey + 32;
+    double* shared = smem + kShortWaves * kShortWaveLds;
+    double2* Wq = reinterpret_cast<double2*>(shared);   // [32] first quadrant of e^{-2 pi i t/128}
+    double* e2tab = shared + 64;
+    double* logTab = e2tab + kExpTab;
+    {
+        const int t = threadIdx.x;
+        if (t < H / 4) Wq[t] = S.wH[t];
+        if (t < kExpTab) e2tab[t] = kExp2Tab[t];
+        if (t < kLogTabEntries * 4) logTab[t] = kLogTabDev.v[t];
+    }
+    // lane constants: Hann values of the lane's two (even, odd) sample pairs, the split twiddle of bin `lane`, and of the
+    // lane's two lines (k = lane, lane + 64): Bark value, quiet threshold, band
+    double he[2], ho[2], zk[2], qk[2];
+    int bk[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = lane + kWave * j;
+        he[j] = S.hann[2 * n]; ho[j] = S.hann[2 * n + 1];
+        zk[j] = S.zb[n]; qk[j] = S.quiet[n]; bk[j] = S.bandOfLine[n];
+    }
+    const double2 wn = S.wN[min(lane, last - 1)];
+    const double xiInv = 1.0 / S.xiDen;
+    const TwQuarter W{Wq, H / 4 - 1, 5};
+    const int nb = S.nBands;
+    __syncthreads();                                    // tables visible (the only workgroup barrier)
+
+    const int64_t first = ((int64_t)blockIdx.x * kShortWaves + wave) * run;
+    for (int it = 0; it < run; ++it) {
+        const int64_t unit = first + it;
+        if (unit >= nUnits) break;                      // wave-uniform
+        const int64_t f = unit / nsig;
+        const int sig = (int)(unit % nsig);
+        if (MODE == 2) {                                // a unit none of whose bands the switch selects: see smr_kernel
+            const bool need = lane < nb && ((sig >= 2) == (msSwitch[f * nb + lane] != 0));
+            if (!__any(need)) continue;
+        }
+        const int64_t off = offsets ? offsets[f] : f * stride;
+        const bool pairAligned = !(off & 1) && !(reinterpret_cast<uintptr_t>(chL) & (2 * sizeof(SampleT) - 1)) &&
+                                 (!chR || !(reinterpret_cast<uintptr_t>(chR) & (2 * sizeof(SampleT) - 1)));
+        // Hann window (window.py:28-45), real FFT through a 128-point complex FFT
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = lane + kWave * j;
+            const double2 eo = load_signal_pair(chL, chR, off + 2 * n, sig, pairAligned);
+            A[n] = make_double2(eo.x * he[j], eo.y * ho[j]);
+        }
+        if (lane < 32) { ratioKey[lane] = 0ull; bandKey[lane] = 0ull; peakKey[lane] = 0ull; }
+        const int scale = oscale[unit];
+        const double* X = lines + unit * M;
+        const double x0 = X[lane], x1 = X[lane + kWave];        // (in flight under the FFT)
+        wave_sync_lds();
+        fft_pass<4, true, TwQuarter, kWave>(A, B, H, 1, W, lane);
+        wave_sync_lds();
+        fft_pass<4, true, TwQuarter, kWave>(B, A, H, 4, W, lane);
+        wave_sync_lds();
+        fft_pass<4, true, TwQuarter, kWave>(A, B, H, 16, W, lane);
+        wave_sync_lds();
+        fft_pass<2, true, TwQuarter, kWave>(B, A, H, 64, W, lane);
+        wave_sync_lds();
+        if (lane < last) {                               // psychoac.py:147-151: intensity of bins 0 .. 27
+            const int k = lane;
+            const double2 zz = A[k];
+            double2 zc = A[(H - k) % H];
+            zc.y = -zc.y;
+            const double2 ev = make_double2(0.5 * (zz.x + zc.x), 0.5 * (zz.y + zc.y));
+            const double2 d = make_double2(zz.x - zc.x, zz.y - zc.y);
+            const double2 od = make_double2(0.5 * d.y, -0.5 * d.x);
+            double2 Xk = cmul(wn, od);
+            Xk.x += ev.x; Xk.y += ev.y;
+            xi[k] = (4. * (Xk.x * Xk.x + Xk.y * Xk.y)) * xiInv;
+        }
+        wave_sync_lds();
+        // tonal maskers: strict 3-point peaks at bins 1 .. 26, in increasing bin order (psychoac.py:160-165)
+        const int p = lane;
+        double y0 = 0.0, y1 = 0.0, y2 = 0.0;
+        if (p >= 1 && p <= last - 2) { y0 = xi[p - 1]; y1 = xi[p]; y2 = xi[p + 1]; }
+        const bool isPeak = p >= 1 && p <= last - 2 && y1 > y0 && y1 > y2;
+        const unsigned long long peaks = __ballot(isPeak);
+        const int nPeaks = __popcll(peaks);
+        if (isPeak) {
+            const int idx = __popcll(peaks & ((1ull << lane) - 1ull));
+            const double s3 = (y0 + y1) + y2;
+            const double fnum = S.binHz * (((p - 1) * y0 + p * y1) + (p + 1) * y2);
+            short_masker(s3, fnum, logTab, mt + 4 * idx);
+        }
+        wave_sync_lds();
+        // psychoac.py:155,166-173: quiet threshold + every masker's spread intensity, in masker order
+        double tot0 = qk[0], tot1 = qk[1];
+        for (int m = 0; m < nPeaks; ++m) {
+            const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
+            const double d0 = zk[0] - zm, d1 = zk[1] - zm;
+            const double u0 = fmax(fabs(d0) - 0.5, 0.0), u1 = fmax(fabs(d1) - 0.5, 0.0);
+            tot0 = fma(I, exp2_tab64<kExpTab>(d0 > 0.0 ? sl : kLowHi * (double)kExpTab, u0, e2tab), tot0);
+            tot1 = fma(I, exp2_tab64<kExpTab>(d1 > 0.0 ? sl : kLowHi * (double)kExpTab, u1, e2tab), tot1);
+        }
+        // psychoac.py:212-217 as in smr_kernel: band maximum of the intensity / threshold ratio, one log10 per band; lines on
+        // the SPL floor take the reference's formula
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const double x = j ? x1 : x0, t = j ? tot1 : tot0;
+            const int bnd = bk[j];
+            const double xs = ldexp(x, scale);                                    // codecThem.py:323 (exact)
+            const double a2 = 2. * (xs * xs) / (1. / 2.);
+            if (!(a2 >= kSplFloorGuard && t >= kSplFloorGuard)) {
+                double thr;
+                atomicMax(&bandKey[bnd], order_key(excess_plain(t, a2, scale, logTab, &thr)));
+            } else {
+                atomicMax(&ratioKey[bnd], (unsigned long long)__double_as_longlong(a2 * recip_nr(t)));
+            }
+            atomicMax(&peakKey[bnd], (unsigned long long)__double_as_longlong(fabs(x)));
+        }
+        wave_sync_lds();
+        if (lane < nb) {
+            double v = bandKey[lane] ? order_value(bandKey[lane]) : -1e300;
+            if (ratioKey[lane]) v = fmax(v, short_band_db(__longlong_as_double((long long)ratioKey[lane]), scale, logTab));
+            smr[unit * nb + lane] = v;
+            bandPeak[unit * nb + lane] = __longlong_as_double((long long)peakKey[lane]);
+        }
+        wave_sync_lds();                                // keys read before the next unit clears them
+    }
+}
+
 }  // namespace
 
 #ifdef MRC_DEBUG_OCC                             // experiment aid: workgroups per CU the runtime grants the long-block kernels
@@ -1405,6 +1593,22 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
         return hipGetLastError();
     }
 #undef MRC_SMR_LAUNCH5
+#ifndef MRC_SMR_SHORT_LEAN                       // 1: short blocks of the hot paths run smr_short_kernel (a wavefront per unit)
+#define MRC_SMR_SHORT_LEAN 1
+#endif
+    if (MRC_SMR_SHORT_LEAN && isShort && !exactSpread && mode != 0 && kExpTab == 64 && S.nBands <= 32 && S.N == 256) {
+        const int64_t nUnits = nFrames * nsig;
+        const int run = (int)std::min<int64_t>(16, std::max<int64_t>(1, nUnits / (kShortWaves * 4096)));
+        const unsigned g = (unsigned)((nUnits + (int64_t)kShortWaves * run - 1) / ((int64_t)kShortWaves * run));
+        const size_t ldsS = (size_t)(kShortWaves * kShortWaveLds + kShortSharedLds) * sizeof(double);
+#define MRC_SMR_SHORT(TY, MD)                                                                                          \
+    hipLaunchKernelGGL((smr_short_kernel<TY, MD>), dim3(g), dim3(kWave * kShortWaves), ldsS, st, S, nUnits, run,        \
+                       (const TY*)chL, (const TY*)chR, stride, offsets, lines, oscale, smr, bandPeak, msSwitch)
+        if (fmt == kSampleI16) { if (mode == 1) MRC_SMR_SHORT(short, 1); else MRC_SMR_SHORT(short, 2); }
+        else { if (mode == 1) MRC_SMR_SHORT(double, 1); else MRC_SMR_SHORT(double, 2); }
+#undef MRC_SMR_SHORT
+        return hipGetLastError();
+    }
 #define MRC_SMR_PICK(EX, TY) do { if (isShort && !EX && mode == 1) MRC_SMR_LAUNCH(EX, TY, 128, 128, 1);               \
                                   else if (isShort && !EX) MRC_SMR_LAUNCH(EX, TY, 128, 128, 0);                      \
                                   else if (M <= 2 * kWave) MRC_SMR_LAUNCH(EX, TY, 128, 0, 0);                        \

@@ -273,6 +273,23 @@ def test_edge_blocks(h):
     assert e["mantissa"].shape == (0, 1024)
 
 
+def test_edge_blocks_short(h):
+    # the short block's own masking kernel (smr_short_kernel: a wavefront per unit, maskers added one by one): digital
+    # silence (no peaks, every SPL on its floor), a full-scale square wave, a loud tone, a tone 80 dB down, one nonzero sample
+    from mrcaudiocodec_amd import synth
+    n = np.arange(256)
+    sil = np.zeros(256)
+    sq = np.where((n // 6) % 2 == 0, 1.0, -1.0) * (32767 * 2.0 / 65535)
+    tone = synth.pcm_to_float(np.rint(30000 * np.sin(2 * np.pi * 3000 * n / 48000)))
+    quiet = synth.pcm_to_float(np.rint(3 * np.sin(2 * np.pi * 1500 * n / 48000)))
+    one = np.zeros(256); one[100] = 2.0 / 65535
+    blocks = np.stack([sil, sq, tone, quiet, one, tone + quiet])
+    _assert_int_parity(h.encode_mono(blocks, 128, 128), fast.encode_mono_batch(blocks, 128, 128))
+    other = blocks[::-1].copy()
+    _assert_int_parity(h.encode_joint(blocks, other, 128, 128), fast.encode_joint_batch(blocks, other, 128, 128), joint=True)
+    _assert_int_parity(h.encode_joint(blocks, blocks.copy(), 128, 128), fast.encode_joint_batch(blocks, blocks.copy(), 128, 128), joint=True)
+
+
 def test_bad_arguments(h):
     from mrcaudiocodec_amd import MrcError
     with pytest.raises(MrcError):
