@@ -533,6 +533,8 @@ def main():
             label = dict(KERNEL_LABEL)
             if (a, b) != (HOP, HOP):
                 label["mdct"] = "mdct_wave_kernel"
+                if (a, b) == (128, 128):
+                    label["smr"] = "smr_short_kernel"
             rr = kernel_report(list(zip(KERNEL_NAMES, km)), abk, o.numel(), {}, label)   # (PMC traffic: per config, below)
             for r in rr:
                 r["shape"] = "%dx%d" % (a, b)
