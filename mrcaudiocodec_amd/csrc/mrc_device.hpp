@@ -265,9 +265,6 @@ __device__ __forceinline__ double2* fft_lds_pow2(double2* A, double2* B, int n, 
     for (int s = 0; s < nrad; ++s) {
         const int R = rad[s];
         if (R == 4) fft_pass<4, true, TwQuarter, NT>(A, B, n, p, W, tid);
-#ifdef MRC_SMR_FFT8
-        else if (R == 8) fft_pass<8, true, TwQuarter, NT>(A, B, n, p, W, tid);
-#endif
         else fft_pass<2, true, TwQuarter, NT>(A, B, n, p, W, tid);
         __syncthreads();
         double2* t = A; A = B; B = t;
@@ -292,35 +289,6 @@ __device__ __forceinline__ double2* fft_lds_1024(double2* A, double2* B, const d
     fft_pass<4, true, TwQuarter, NT>(A, B, 1024, 256, W, tid);
     __syncthreads();
     return B;
-}
-// The same five passes IN PLACE: a pass reads its four points, the whole workgroup meets at a barrier, then it writes them
-// where the Stockham pass would have put them in the other buffer -- one buffer instead of two (16 KB of LDS less for the long
-// block) for one more barrier per pass.  Same operations in the same order as fft_lds_1024: bit-identical results.
-template <int NT = kThreads>
-__device__ __forceinline__ void fft_inplace_1024(double2* F, const double2* wq, int tid) {
-    static_assert(NT == 256, "one radix-4 butterfly per thread and pass");
-    const TwQuarter W{wq, 255, 8};
-    constexpr int n = 1024, R = 4, T = n / R;
-    const int i = tid;
-#pragma unroll
-    for (int pass = 0; pass < 5; ++pass) {
-        const int p = 1 << (2 * pass);
-        const int tws = n / (p * R);
-        const int k = i & (p - 1);
-        const int j = (i >> (2 * pass)) * (p * R) + k;
-        double2 u[R];
-#pragma unroll
-        for (int r = 0; r < R; ++r) u[r] = F[i + r * T];
-        if (pass != 0) {
-#pragma unroll
-            for (int r = 1; r < R; ++r) u[r] = cmul(u[r], W(k * r * tws, (4 * r + R - 1) / R));
-        }
-        butterfly<R>(u);
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < R; ++q) F[j + q * p] = u[q];
-        __syncthreads();
-    }
 }
 // ... and the 128-point transform of the short block (4 x 4 x 4 x 2)
 template <int NT = kThreads>

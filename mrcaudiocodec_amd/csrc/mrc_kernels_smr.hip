@@ -99,19 +99,10 @@ __device__ __forceinline__ double exp2_poly(double f) {
 // 2^(sT*u/T) for the spreading loop, table driven (T = kExpTab entries per octave, sT = slope in 1/T bit per Bark):
 // n = rint(sT*u) splits into k = n / T (exponent), j = n mod T (entry of the 2^(j/T) table in LDS) and a remainder
 // g = sT*u - n in [-1/2, 1/2] (exact, by fma) whose 2^(g/T) = exp(g ln2/T) is a Taylor polynomial (T = 64: degree 5,
-// remainder < 3.5e-17; T = 32: degree 6, remainder < 3.5e-18).  sT*u == 0 gives exactly 1 (a line inside +-1/2 Bark
+// remainder < 3.5e-17).  sT*u == 0 gives exactly 1 (a line inside +-1/2 Bark
 // gets exactly the masker's intensity).  Requires |sT*u| < 2^31 (here it is < 16000).
-// T = 64 is the default.  T = 32 (-DMRC_EXP_TAB=32) makes the lookups conflict-free -- 32 entries of 8 bytes fill the
-// 64 LDS banks exactly once, whereas 64 entries put j and j + 32 on one bank pair, a 2-4 way conflict on most lookups
-// and 43 % of the kernel's LDS cycles -- but measured 1.4 % SLOWER (5.02 vs 4.95 ms per 131 072 frames, round 2): the
-// LDS pipe is not what the waves wait for, and the extra fma is paid on every pair.
-#ifndef MRC_EXP_TAB
-#define MRC_EXP_TAB 64
-#endif
-constexpr int kExpTab = MRC_EXP_TAB;
-constexpr int kExpTabShift = MRC_EXP_TAB == 32 ? 5 : 6;
-[[maybe_unused]] constexpr double kExpTabD = (double)MRC_EXP_TAB;   // (the MFMA experiment)
-static_assert(MRC_EXP_TAB == 32 || MRC_EXP_TAB == 64, "2^x table: 32 or 64 entries per octave");
+constexpr int kExpTab = 64;
+constexpr int kExpTabShift = 6;
 // an SPL reaches its -30 dB floor at an intensity of 10^-12.6 (psychoac.py:8-12); above this guard it does not
 constexpr double kSplFloorGuard = 1e-12;
 // T = 256 (the long block's sweep, MRC_EXP_TAB_LONG): a table four times as fine takes one term off the polynomial
@@ -119,7 +110,7 @@ constexpr double kSplFloorGuard = 1e-12;
 #ifndef MRC_EXP_TAB_LONG
 #define MRC_EXP_TAB_LONG 256
 #endif
-template <int T = MRC_EXP_TAB>
+template <int T = kExpTab>
 __device__ __forceinline__ double exp2_tab64(double sT, double u, const double* __restrict__ tab) {
     const double shifter = 0x1.8p52;
     const double tt = fma(sT, u, shifter);
@@ -133,37 +124,17 @@ __device__ __forceinline__ double exp2_tab64(double sT, double u, const double* 
         p = fma(p, g, 1.0);
         return ldexp(p * tab[n & 255], n >> 8);
     }
-#if MRC_EXP_TAB == 32
-    double p = fma(0x1.430912f86c787p-43, g, 0x1.5d87fe78a6731p-35);
-    p = fma(p, g, 0x1.3b2ab6fba4e77p-27);
-    p = fma(p, g, 0x1.c6b08d704a0c0p-20);
-    p = fma(p, g, 0x1.ebfbdff82c58fp-13);
-    p = fma(p, g, 0x1.62e42fefa39efp-6);
-#else
     double p = fma(0x1.5d87fe78a6731p-40, g, 0x1.3b2ab6fba4e77p-31);
     p = fma(p, g, 0x1.c6b08d704a0c0p-23);
     p = fma(p, g, 0x1.ebfbdff82c58fp-15);
     p = fma(p, g, 0x1.62e42fefa39efp-7);
-#endif
     p = fma(p, g, 1.0);
     // (the table as two arrays of 32-bit halves -- entry j of either in bank j, conflict-free for any index pattern -- was
     // measured in round 3: 4.60 against 4.54 ms; like the 32-entry table of round 2 it removes conflicts the waves do not wait for)
     return ldexp(p * tab[n & (kExpTab - 1)], n >> kExpTabShift);
 }
 
-// 2^(j/T), j = 0..T-1, correctly rounded
-#if MRC_EXP_TAB == 32
-__constant__ double kExp2Tab[kExpTab] = {
-    0x1.0000000000000p+0, 0x1.059b0d3158574p+0, 0x1.0b5586cf9890fp+0, 0x1.11301d0125b51p+0,
-    0x1.172b83c7d517bp+0, 0x1.1d4873168b9aap+0, 0x1.2387a6e756238p+0, 0x1.29e9df51fdee1p+0,
-    0x1.306fe0a31b715p+0, 0x1.371a7373aa9cbp+0, 0x1.3dea64c123422p+0, 0x1.44e086061892dp+0,
-    0x1.4bfdad5362a27p+0, 0x1.5342b569d4f82p+0, 0x1.5ab07dd485429p+0, 0x1.6247eb03a5585p+0,
-    0x1.6a09e667f3bcdp+0, 0x1.71f75e8ec5f74p+0, 0x1.7a11473eb0187p+0, 0x1.82589994cce13p+0,
-    0x1.8ace5422aa0dbp+0, 0x1.93737b0cdc5e5p+0, 0x1.9c49182a3f090p+0, 0x1.a5503b23e255dp+0,
-    0x1.ae89f995ad3adp+0, 0x1.b7f76f2fb5e47p+0, 0x1.c199bdd85529cp+0, 0x1.cb720dcef9069p+0,
-    0x1.d5818dcfba487p+0, 0x1.dfc97337b9b5fp+0, 0x1.ea4afa2a490dap+0, 0x1.f50765b6e4540p+0
-};
-#else
+// 2^(j/64), j = 0..63, correctly rounded
 __constant__ double kExp2Tab[kExpTab] = {
     0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
     0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
@@ -182,7 +153,6 @@ __constant__ double kExp2Tab[kExpTab] = {
     0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
     0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0
 };
-#endif
 
 // 2^(j/256), j = 0..255, correctly rounded (the long block's table)
 __constant__ double kExp2Tab256[256] = {
@@ -374,62 +344,6 @@ __device__ __forceinline__ double far_group(const double* __restrict__ mt, int n
 }
 
 
-// MRC_FAR_MFMA = 1: far-field sums through v_mfma_f64_16x16x4 (below).  Correct (all GPU tests pass) and 2 200 VALU
-// instructions per frame shorter, but 19 % SLOWER (smr_kernel 5.94 vs 4.97 ms per 131 072 frames, round 2): on MI355X an
-// fp64 MFMA holds the SIMD's fp64 pipe for its 64 cycles -- tools/valu_rates.hip: a dependent chain issues one per 64
-// cycles, and 1 MFMA + 8 independent v_fma_f64 take 106 cycles, the sum of the two, with 1, 2 or 4 waves per SIMD -- so the
-// ~370 matrix instructions per frame cost what 5 900 fp64 VALU instructions would.  The matrix pipe is no second fp64 engine
-// on this chip (78.6 TFLOP/s either way); kept as a build option for the record.
-#ifndef MRC_FAR_MFMA
-#define MRC_FAR_MFMA 0
-#endif
-#if MRC_FAR_MFMA
-// ---- far field on the matrix pipe.
-// A RUN of adjacent chunks (all taken by one wave) shares ONE expansion centre C: with e_m = I_m 2^(s_m (C - 1/2 - z_m)),
-// a_m = s_m ln2 and A the middle slope, the far maskers of a line at distance d = z - C from the centre sum to
-//   exp(A d) sum_j d^j S_j,   S_j = 1/j! sum_{m < nFar} e_m (a_m - A)^j,
-// and the runs's chunks differ only in nFar (non-decreasing with the chunk): the S_j of chunk c+1 are those of chunk c plus
-// the maskers in between.  So the maskers are walked ONCE per run, 64 at a time (a lane per masker: one 2^x and the
-// powers of a_m - A), in SEGMENTS that end where a chunk's nFar is reached, and the per-lane terms are summed over the
-// wave by v_mfma_f64_16x16x4: with the lane's term as the A operand (A[i][k] = lane 16 k + i) and a 0/1 selector as the
-// B operand (B[k][c] = [c == j]) the accumulator column j collects sum_k term_j(16 k + i) for the 16 rows i -- no VALU
-// additions, no cross-lane shuffles, and the accumulator simply keeps running from one chunk of the run to the next.
-// When a chunk's nFar is reached, the four accumulator registers of a lane are added, scaled by 1/j! and summed over the
-// rows by one more MFMA against a matrix of ones: every lane then holds S_(lane & 15), and the polynomial is evaluated
-// with v_fmac_f64 ... row_newbcast:j (the coefficient comes straight from lane j of the 16-lane row).
-// The VALU keeps: one 2^x per masker and RUN (not per chunk), and 3 instructions per order and segment.
-typedef double double4v __attribute__((__vector_size__(4 * sizeof(double))));
-// largest |x| = (half slope range) x (half Bark span of the run) for NB = 8 / 12 / 16 coefficients: truncated tail
-// x^NB / NB! e^x below 1e-15 of each term
-constexpr double kRunLimit8 = 0.0499, kRunLimit12 = 0.2903, kRunLimit16 = 0.7494;
-
-template <int J>
-__device__ __forceinline__ double fmac_row_bcast(double acc, double coef, double x) {
-    // acc += (coef of lane J of this lane's 16-lane row) * x
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(coef), "v"(x), "n"(J));
-    return acc;
-}
-template <int NB, int J = 1>
-__device__ __forceinline__ double row_poly(double p, double coef, double dpow, double d) {
-    if constexpr (J < NB) {
-        dpow *= d;
-        p = fmac_row_bcast<J>(p, coef, dpow);
-        return row_poly<NB, J + 1>(p, coef, dpow, d);
-    } else {
-        return p;
-    }
-}
-template <int NB, int J = 0>
-__device__ __forceinline__ void mfma_terms(double4v& D, double t, double da, int lane15) {
-    if constexpr (J < NB) {
-        const double sel = (lane15 == J) ? 1.0 : 0.0;
-        D = __builtin_amdgcn_mfma_f64_16x16x4f64(t, sel, D, 0, 0, 0);
-        if constexpr (J + 1 < NB) t *= da;
-        mfma_terms<NB, J + 1>(D, t, da, lane15);
-    }
-}
-#endif
-
 // 1/x for a finite positive normal x: hardware estimate + two Newton steps (relative error ~2^-52; NOT the correctly
 // rounded quotient -- used by the fast spreading mode only, where one more rounding per masker / line is inside what the
 // FFT in front of it already differs from the reference's by; the EXACT mode divides like the reference)
@@ -587,40 +501,18 @@ __device__ unsigned long long gPhaseCycles[16];
 // immediates; same arithmetic, same results.  0: any shape, dimensions from DevShape.
 // MODE: what the hot paths fix at compile time -- 1: mono (one signal per frame, every band wanted, no thresholds out, band
 // peaks out); 2: joint stereo with the M/S switch known (four signals, the rest alike); 0: all of it at run time.
-// PLAN5 (long blocks on the hot paths only): the LDS plan that lets FIVE workgroups share a CU instead of four -- 31.6 KB
-// instead of 40.2 KB of dynamic LDS, under a 96-register cap (smr_kernel5).  The 1024-point FFT runs in place (one
-// buffer), and one region of 1024 doubles is handed from the FFT twiddles to the intensity spectrum to the Bark grid to the
-// prefix sums, as each dies:
-//   [0, 2048)     F : FFT data; then the masker table (4 doubles x <= 461 maskers), bandKey / peakKey [1848, 1912),
-//                     ratioKey [1952, 1984), 2^x table [1984, 2048)
-//   [2048, 2561)  C : cntArr, nUpArr (2 x 1026 uint16)
-//   [2561, 3585)  X : twiddle quadrant -> xi (925) -> Bark grid zb (1024) -> piHi, piLo (2 x 462)
-//   [3585, 3713)  Y : log10 table during the masker-table phase (afterwards read from global memory: rare uses only)
-//   [3485, 3947)  sc: suffix sums, after the Bark grid is dead (the tail of X and what Y held)
-// The peak compaction writes each peak's three intensities and its bin into the peak's masker-table slot (no peak-bin array;
-// the spectrum is dead one phase earlier, which is what frees X for the Bark grid).  Same arithmetic, same results.
-constexpr int kP5C = 2048, kP5X = 2561, kP5Y = 3585, kP5Sc = 3485, kP5Total = 3947, kP5Pi = 462;
-constexpr int kP5Keys = 1848;                    // bandKey, peakKey: [1848, 1912), behind the last masker (4 x 462 = 1848)
-static_assert(kP5Keys + 2 * kMaxBands <= 2048 - kExpTab - kMaxBands, "PLAN5: keys overlap ratioKey");
-static_assert(kP5Total * 8 + 128 <= 25 * 1280, "PLAN5: more than a fifth of the CU's LDS");
-
-template <bool EXACT, class SampleT, int NT, int DIM, int MODE, bool PLAN5>
+template <bool EXACT, class SampleT, int NT, int DIM, int MODE>
 __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT* __restrict__ chL,
                                          const SampleT* __restrict__ chR, int64_t stride,
                                          const int64_t* __restrict__ offsetsArg, const double* __restrict__ lines,
                                          const int* __restrict__ oscale, double* __restrict__ smr,
                                          double* __restrict__ threshArg, double* __restrict__ bandPeakArg,
                                          const int* __restrict__ msSwitch, SmrLds layArg) {
-    static_assert(!PLAN5 || (DIM == 1024 && !EXACT && MODE != 0 && NT == 256), "PLAN5: long blocks, fast mode, hot paths");
     extern __shared__ double smem[];
-    const SmrLds lay = PLAN5 ? SmrLds{kP5X, kP5Y, kP5X} : DIM ? smr_layout(DIM, DIM, DIM - 100, nullptr) : layArg;
+    const SmrLds lay = DIM ? smr_layout(DIM, DIM, DIM - 100, nullptr) : layArg;
     __shared__ int waveCnt[NT / kWave];
     // per-band running max of the excess (order-preserving key), per-band max |X| (the bit pattern of |x| orders like |x|).
-    // PLAN5 keeps them in the gap of region F behind the masker table (the LDS of a CU is handed out in 1280-byte granules:
-    // a fifth of it is 25 granules = 32 000 B for dynamic + static together), zeroed once the FFT is done.
-    __shared__ unsigned long long bandKeyS[PLAN5 ? 1 : kMaxBands], peakKeyS[PLAN5 ? 1 : kMaxBands];
-    unsigned long long* const bandKey = PLAN5 ? reinterpret_cast<unsigned long long*>(smem + kP5Keys) : bandKeyS;
-    unsigned long long* const peakKey = PLAN5 ? bandKey + kMaxBands : peakKeyS;
+    __shared__ unsigned long long bandKey[kMaxBands], peakKey[kMaxBands];
     __shared__ unsigned long long slopeKey[2];          // min / max upper slope over the frame's maskers (keys)
     __shared__ unsigned char needBand[kMaxBands];       // joint blocks: does the encoder use THIS signal's SMR of the band?
     const int tid = threadIdx.x;
@@ -661,15 +553,14 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     }
     const int64_t off = offsets ? offsets[f] : f * stride;
     double2* A = (double2*)smem;                        // [H]
-    double2* B = A + H;                                 // [H]  (PLAN5: not used, the FFT runs in place)
-    double* xi = PLAN5 ? smem + kP5X : smem + 4 * H;    // [peakLast + 1] intensity spectrum; later the suffix sums
+    double2* B = A + H;                                 // [H]
+    double* xi = smem + 4 * H;    // [peakLast + 1] intensity spectrum; later the suffix sums
     // region B is free once the spectrum is in xi: peak bins, then per-line masker counts (filled below)
-    short* pkBin = reinterpret_cast<short*>(smem + 2 * H);              // [<= peakLast/2 + 1] peak bins, increasing (not PLAN5)
-    unsigned short* cntArr = PLAN5 ? reinterpret_cast<unsigned short*>(smem + kP5C)
-                                   : reinterpret_cast<unsigned short*>(pkBin + ((last / 2 + 5) & ~3));   // [M + 1]
+    short* pkBin = reinterpret_cast<short*>(smem + 2 * H);              // [<= peakLast/2 + 1] peak bins, increasing
+    unsigned short* cntArr = reinterpret_cast<unsigned short*>(pkBin + ((last / 2 + 5) & ~3));   // [M + 1]
     unsigned short* nUpArr = cntArr + (M + 2);                           // [M + 1]
-    double* piHi = PLAN5 ? smem + kP5X : reinterpret_cast<double*>(nUpArr + (M + 2));   // [<= peakLast/2 + 2] prefix sums of
-    double* piLo = piHi + (PLAN5 ? kP5Pi : last / 2 + 2);                //   the masker intensities, double-double (hi, lo)
+    double* piHi = reinterpret_cast<double*>(nUpArr + (M + 2));   // [<= peakLast/2 + 2] prefix sums of
+    double* piLo = piHi + (last / 2 + 2);                //   the masker intensities, double-double (hi, lo)
 
 #ifdef MRC_PROFILE_PHASES
     long long tPhase_ = clock64();
@@ -678,9 +569,9 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     // is one long stream of VALU work.  Waves of the four workgroups that share a SIMD are in different phases: the
     // ones in the latency-bound part get issue priority, so their chain is not stretched by a neighbour's sweep.
     __builtin_amdgcn_s_setprio(MRC_FRONT_PRIO);
-    if (!PLAN5 && tid < kMaxBands) bandKey[tid] = 0ull; // below every key; visible after the first barrier
+    if (tid < kMaxBands) bandKey[tid] = 0ull; // below every key; visible after the first barrier
     if (tid < 2) slopeKey[tid] = tid ? 0ull : ~0ull;
-    if (!PLAN5 && tid < kMaxBands) peakKey[tid] = 0ull;
+    if (tid < kMaxBands) peakKey[tid] = 0ull;
     // ms_stereo.py:70-81 (OverallSMRs) keeps, per band, either the L / R pair of SMRs or the M / S pair: the other two
     // never reach the bit allocation.  With the switch known (it only needs the MDCT lines) the sweep below leaves out
     // the 64-line chunks none of whose bands want this signal -- half of all (signal, band) pairs of a stereo frame.
@@ -689,13 +580,13 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     const double* zbS = smem + lay.zbOff;               // staged after the FFT (the area is FFT scratch / dead)
     // 2^(j/T): T = 64 in the tail of region A, behind the masker table; the long block's sweep: T = 256, in the half of the
     // spectrum area the suffix sums leave free (staged when the spectrum is dead, with the scans)
-    constexpr int TAB = (DIM == 1024 && !EXACT && !PLAN5 && NT == 256 && MRC_EXP_TAB == 64) ? MRC_EXP_TAB_LONG : kExpTab;
+    constexpr int TAB = (DIM == 1024 && !EXACT && NT == 256) ? MRC_EXP_TAB_LONG : kExpTab;
     constexpr int kTabLongOff = 464;                    // (doubles behind the start of the spectrum area; sc takes <= 462)
     const double* e2tab = TAB == kExpTab ? smem + 2 * H - kExpTab : smem + 4 * H + kTabLongOff;
     // per-band max of (line intensity / masked threshold) as the bit pattern of a positive double; in front of e2tab
     unsigned long long* ratioKey = reinterpret_cast<unsigned long long*>(smem + 2 * H - kExpTab - kMaxBands);
-    const double* logTabLds = smem + lay.logOff;        // (PLAN5: valid through the masker-table phase only)
-    const double* logTab = PLAN5 ? kLogTabDev.v : logTabLds;   // the sweep's rare uses and the 25 band conversions
+    const double* logTabLds = smem + lay.logOff;
+    const double* logTab = logTabLds;
     // Hann window (window.py:28-45) and real FFT through an H = N/2 point complex FFT.  All global loads of a
     // thread are issued before the first use: one memory round trip per phase instead of one per iteration.
     constexpr int kPre = 4;
@@ -739,20 +630,15 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         for (int t = tid; t < H / 4; t += NT) Wq[t] = S.wH[t];
         __syncthreads();
         MRC_PHASE(0); MRC_STOP(0);
-#ifndef MRC_SMR_FFT8
-        if constexpr (PLAN5) { fft_inplace_1024<NT>(A, Wq, tid); T = A; }
-        else if (LONG && NT == 256) T = fft_lds_1024<NT>(A, B, Wq, tid);
+        if (LONG && NT == 256) T = fft_lds_1024<NT>(A, B, Wq, tid);
         else if (DIM == 128) T = fft_lds_128<NT>(A, B, Wq, tid);
         else
-#endif
         T = fft_lds_pow2<NT>(A, B, H, S.radH, S.nRadH, TwQuarter{Wq, H / 4 - 1, 31 - __clz(H / 4)}, tid);
     } else {
         __syncthreads();
         MRC_PHASE(0); MRC_STOP(0);
-#ifndef MRC_SMR_FFT8
         if (DIM == 576) T = fft_lds_576<NT>(A, B, S.wH, tid);
         else
-#endif
         T = fft_lds_global<NT>(A, B, H, S.radH, S.nRadH, S.wH, tid);
     }
     MRC_PHASE(1); MRC_STOP(1);
@@ -780,7 +666,7 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     __syncthreads();                                    // T (in A or B) is dead from here on
     MRC_PHASE(2); MRC_STOP(2);
     if (!EXACT) {                                       // stage the Bark grid and the log10 table (used after 2 barriers)
-        if (!PLAN5) {                                   // (PLAN5: the Bark grid takes xi's place once the peaks are compacted)
+        {
             double* zw = smem + lay.zbOff;
 #pragma unroll
             for (int u = 0; u < kPre; ++u)
@@ -790,7 +676,6 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         if (tid < kLogTabEntries * 4) smem[lay.logOff + tid] = logPre;
         if (TAB == kExpTab && tid < kExpTab) smem[2 * H - kExpTab + tid] = e2Pre;
         if (tid < kMaxBands) ratioKey[tid] = 0ull;
-        if (PLAN5 && tid < 2 * kMaxBands) bandKey[tid] = 0ull;           // (bandKey and peakKey, adjacent)
     }
 
     // tonal maskers: strict 3-point peaks at bins p = 1 .. last-2, kept in increasing bin order.
@@ -817,35 +702,17 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     // table entry is computed by full waves instead of the few lanes that happen to own a peak
     for (int p = p0; p < p1; ++p)
         if (xi[p] > xi[p - 1] && xi[p] > xi[p + 1]) {
-            if (PLAN5) {                                 // the peak's intensities and bin go straight into its table slot
-                double* e = mt + 4 * before++;
-                e[0] = xi[p - 1]; e[1] = xi[p]; e[2] = xi[p + 1]; e[3] = (double)p;
-            } else {
-                pkBin[before++] = (short)p;
-            }
+            pkBin[before++] = (short)p;
         }
     if (!EXACT)
         for (int k = tid; k <= M; k += NT) { cntArr[k] = 0; nUpArr[k] = 0; }
     __syncthreads();
-    if (PLAN5) {                                        // xi is dead: its region takes the Bark grid of the lines
-        double* zw = smem + lay.zbOff;
-#pragma unroll
-        for (int u = 0; u < kPre; ++u) zw[tid + u * NT] = zbPre[u];      // (kPre * NT = M = 1024)
-        __syncthreads();
-    }
     MRC_PHASE(3); MRC_STOP(3);
     double slLo = 1e300, slHi = -1e300;                 // this thread's maskers: range of the upper slope
     for (int mi = tid; mi < nPeaks; mi += NT) {
         const int before = mi;
-        int p;
-        double x0, x1, x2;
-        if (PLAN5) {
-            const double* e = mt + 4 * mi;
-            x0 = e[0]; x1 = e[1]; x2 = e[2]; p = (int)e[3];
-        } else {
-            p = pkBin[mi];
-            x0 = xi[p - 1]; x1 = xi[p]; x2 = xi[p + 1];
-        }
+        const int p = pkBin[mi];
+        const double x0 = xi[p - 1], x1 = xi[p], x2 = xi[p + 1];
         {
             double s3 = (x0 + x1) + x2;
             double level = EXACT ? spl_db(s3) : spl_db_tab(s3, logTabLds);   // psychoac.py:164
@@ -949,7 +816,7 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         }
     } else {
         // suffix sums of the lower-side constants: sc[m] = sum_{j >= m} I_j 2^(b z_j), sc[nPeaks] = 0
-        double* sc = PLAN5 ? smem + kP5Sc : xi;         // xi is dead (all peak reads happened before the barrier)
+        double* sc = xi;                                 // xi is dead (all peak reads happened before the barrier)
         if (TAB != kExpTab) smem[4 * H + kTabLongOff + tid] = e2Pre;      // (NT = 256 = TAB: an entry per thread)
         // four independent scans, dealt to the workgroup's waves (4 waves: one each; 2 waves: two each)
         for (int task = wave; task < 4; task += NT / kWave) {
@@ -1040,21 +907,7 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         // global-load latency is never exposed between the loops of a chunk)
         struct LineConst { double z, quiet, lowE, x; int bnd; };
         const int waveU = __builtin_amdgcn_readfirstlane(wave);          // (uniform: chunk indices stay in SGPRs)
-#if MRC_FAR_MFMA
-        // chunks are dealt to the waves in adjacent PAIRS (pair s of a wave: cheap low pairs alternate with expensive high
-        // ones), so that a far-field run can span two -- for the wave that gets the middle of the spectrum, four -- chunks;
-        // blocks with fewer than two chunks per wave keep single chunks
-        const bool pairMode = nChunks >= 2 * nWaves;
-        auto chunk_of = [&](int i) {
-            if (pairMode) {
-                const int sIdx = i >> 1;
-                return 2 * (sIdx * nWaves + ((sIdx & 1) ? (nWaves - 1 - waveU) : waveU)) + (i & 1);
-            }
-            return i * nWaves + ((i & 1) ? (nWaves - 1 - waveU) : waveU);
-        };
-#else
         auto chunk_of = [&](int i) { return i * nWaves + ((i & 1) ? (nWaves - 1 - waveU) : waveU); };
-#endif
         auto load_consts = [&](int i) {
             const int kc = min(chunk_of(i) * kWave + lane, M - 1);
             return LineConst{S.zb[kc], S.quiet[kc], S.lowE[kc], X[kc], S.bandOfLine[kc]};
@@ -1082,79 +935,6 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         __builtin_amdgcn_s_setprio(MRC_FAR_PRIO);
         double far0 = 0.0, far1 = 0.0, far2 = 0.0, far3 = 0.0;
         unsigned farMask = 0;                            // bit u: chunk u of the round took the far field
-#if MRC_FAR_MFMA
-        {
-            const int lane15 = lane & 15;
-            const double invFact = kInvFactorial[lane15];
-            // maskers more than 1/2 Bark below every line of chunk c -- 0: the chunk takes no far field
-            auto far_count = [&](int c) -> int {
-                const int kc = min(c * kWave + lane, M - 1);
-                if (haveSwitch && !__any(needBand[S.bandOfLine[kc]])) return 0;                  // (see needBand)
-                const int nf = __builtin_amdgcn_readfirstlane((int)nUpArr[kc]);    // nUp of the chunk's first line
-                return (nf < kFarMinMaskers || (MRC_PROFILE_SKIP & 1)) ? 0 : nf;
-            };
-            for (int u = 0; u < 4;) {
-                const int c = chunk_of(i0 + u);
-                if (c >= nChunks) break;
-                const int nf = far_count(c);
-                const double zFirst = S.zb[c * kWave];
-                double zLast = S.zb[min(c * kWave + kWave - 1, M - 1)];
-                if (!nf || spreadHalf * (0.5 * (zLast - zFirst)) > kRunLimit16) { ++u; continue; }
-                // extend the run over the adjacent chunks of this wave while the expansion still converges
-                int uEnd = u, nEnd = nf;
-                while (uEnd + 1 < 4) {
-                    const int c2 = chunk_of(i0 + uEnd + 1);
-                    if (c2 != c + (uEnd + 1 - u) || c2 >= nChunks) break;
-                    const int nf2 = far_count(c2);
-                    const double zLast2 = S.zb[min(c2 * kWave + kWave - 1, M - 1)];
-                    if (!nf2 || spreadHalf * (0.5 * (zLast2 - zFirst)) > kRunLimit16) break;
-                    zLast = zLast2; nEnd = nf2; ++uEnd;
-                }
-                const double need = spreadHalf * (0.5 * (zLast - zFirst));
-                const double C = 0.5 * (zFirst + zLast), cq = C - 0.5;
-                const int nb = need <= kRunLimit8 ? 8 : need <= kRunLimit12 ? 12 : 16;
-                double4v D = {0.0, 0.0, 0.0, 0.0};
-                int cur = u, curEnd = nf;
-                for (int m0 = 0; m0 < nEnd && cur <= uEnd; m0 += kWave) {
-                    const int m = m0 + lane, mm = min(m, nEnd - 1);
-                    const double I = mt[4 * mm], zm = mt[4 * mm + 1], sl = mt[4 * mm + 2];
-                    const double e = (m < nEnd) ? I * exp2_tab64(sl, cq - zm, e2tab) : 0.0;
-                    const double da = (sl - slMid) * (0.6931471805599453094 / kExpTabD);   // slope offset in nats per Bark
-                    int segLo = m0;
-                    while (cur <= uEnd) {
-                        const int segHi = min(curEnd, m0 + kWave);
-                        if (segHi > segLo) {
-                            const double t = (m >= segLo && m < segHi) ? e : 0.0;
-                            if (nb == 8) mfma_terms<8>(D, t, da, lane15);
-                            else if (nb == 12) mfma_terms<12>(D, t, da, lane15);
-                            else mfma_terms<16>(D, t, da, lane15);
-                            segLo = segHi;
-                        }
-                        if (curEnd > m0 + kWave) break;          // the rest of this chunk's maskers: next 64
-                        // chunk `cur` has all its far maskers: coefficients, then the polynomial on its lines
-                        const int cc = chunk_of(i0 + cur);
-                        const double z = S.zb[min(cc * kWave + lane, M - 1)];
-                        const double d = z - C;
-                        const double4v Z = {0.0, 0.0, 0.0, 0.0};
-                        const double part = ((D[0] + D[1]) + (D[2] + D[3])) * invFact;
-                        const double coef = __builtin_amdgcn_mfma_f64_16x16x4f64(1.0, part, Z, 0, 0, 0)[0];
-                        double p = fmac_row_bcast<0>(0.0, coef, 1.0);
-                        p = (nb == 8) ? row_poly<8>(p, coef, 1.0, d) : (nb == 12) ? row_poly<12>(p, coef, 1.0, d)
-                                                                                     : row_poly<16>(p, coef, 1.0, d);
-                        const double val = p * exp2_tab64(slMid, d, e2tab);
-                        farMask |= 1u << cur;
-                        far0 = cur == 0 ? val : far0;
-                        far1 = cur == 1 ? val : far1;
-                        far2 = cur == 2 ? val : far2;
-                        far3 = cur == 3 ? val : far3;
-                        ++cur;
-                        if (cur <= uEnd) curEnd = far_count(chunk_of(i0 + cur));
-                    }
-                }
-                u = uEnd + 1;
-            }
-        }
-#else
         // (a block of DIM lines has at most (DIM - 101) / 2 maskers: a short block's 13 never reach kFarMinMaskers, so its
         // instance carries no far-field code -- and fits the registers of eight waves per SIMD)
         constexpr bool kHaveFar = DIM == 0 || (DIM - 101) / 2 >= kFarMinMaskers;
@@ -1204,7 +984,6 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
             far2 = u == 2 ? acc : far2;
             far3 = u == 3 ? acc : far3;
         }
-#endif
         MRC_PHASE(7);
         // ---- pass 2.  The per-line constants of the NEXT chunk are loaded while this one is computed (loop-carried,
         // so the global-load latency is never exposed between the loops of a chunk)
@@ -1331,18 +1110,8 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
                                                        const int* __restrict__ oscale, double* __restrict__ smr,
                                                        double* __restrict__ threshArg, double* __restrict__ bandPeakArg,
                                                        const int* __restrict__ msSwitch, SmrLds layArg) {
-    smr_body<EXACT, SampleT, NT, DIM, MODE, false>(S, nsigArg, chL, chR, stride, offsetsArg, lines, oscale, smr, threshArg,
+    smr_body<EXACT, SampleT, NT, DIM, MODE>(S, nsigArg, chL, chR, stride, offsetsArg, lines, oscale, smr, threshArg,
                                                    bandPeakArg, msSwitch, layArg);
-}
-
-// the long block of the hot paths under PLAN5: five workgroups of four waves per CU (<= 96 VGPRs, 31.6 KB of LDS)
-template <class SampleT, int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void smr_kernel5(
-    DevShape S, const SampleT* __restrict__ chL, const SampleT* __restrict__ chR, int64_t stride,
-    const int64_t* __restrict__ offsetsArg, const double* __restrict__ lines, const int* __restrict__ oscale,
-    double* __restrict__ smr, double* __restrict__ bandPeakArg, const int* __restrict__ msSwitch) {
-    smr_body<false, SampleT, 256, 1024, MODE, true>(S, MODE == 1 ? 1 : 4, chL, chR, stride, offsetsArg, lines, oscale, smr,
-                                                    nullptr, bandPeakArg, msSwitch, SmrLds{0, 0, 0});
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1526,16 +1295,6 @@ __global__ __launch_bounds__(kWave * kShortWaves) __attribute__((amdgpu_waves_pe
 
 }  // namespace
 
-#ifdef MRC_DEBUG_OCC                             // experiment aid: workgroups per CU the runtime grants the long-block kernels
-extern "C" int mrc_debug_smr_occupancy(int* out2) {
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&out2[0], smr_kernel5<short, 1>, 256, (size_t)kP5Total * 8);
-    if (e == hipSuccess)
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&out2[1], smr_kernel<false, short, 256, 1024, 1>, 256,
-                                                         (size_t)(4 * 1024 + 925) * 8);
-    return e == hipSuccess ? 0 : -1;
-}
-#endif
-
 #ifdef MRC_PROFILE_PHASES
 extern "C" int mrc_debug_phase_cycles(unsigned long long* out16, int reset) {
     hipError_t e = hipDeviceSynchronize();
@@ -1576,23 +1335,6 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
     const bool isTrans = H == 576 && M == 576 && S.peakLast == 476 && lay.twOff < 0 && MRC_SMR_THREADS == 256;
     // the hot paths: mono, and (long blocks) joint stereo with the switch known; no thresholds wanted
     const int mode = (thresh || !bandPeak) ? 0 : (nsig == 1 && !msSwitch) ? 1 : (nsig == 4 && msSwitch) ? 2 : 0;
-// MRC_SMR_PLAN5=1: long blocks of the hot paths run smr_kernel5 (5 workgroups per CU; the runtime's occupancy query confirms
-// the fifth).  Measured, round 3: 4.567 vs 4.548 ms per 131 072 mono frames, 9.32 vs 9.07 ms per joint step of 65 536 -- the
-// fifth workgroup buys nothing (the kernel is bound by VALU issue, and the 96-register cap and the extra barriers of the
-// in-place FFT cost what the occupancy gives), so the four-workgroup plan stays the default.  Results are identical.
-#ifndef MRC_SMR_PLAN5
-#define MRC_SMR_PLAN5 0
-#endif
-#define MRC_SMR_LAUNCH5(TY, MD)                                                                                       \
-    hipLaunchKernelGGL((smr_kernel5<TY, MD>), grid, dim3(256), (size_t)kP5Total * sizeof(double), st, S, (const TY*)chL, \
-                       (const TY*)chR, stride, offsets, lines, oscale, smr, bandPeak, msSwitch)
-    const bool plan5 = MRC_SMR_PLAN5 && isLong && !exactSpread && mode != 0 && S.nBands <= kMaxBands;
-    if (plan5) {
-        if (fmt == kSampleI16) { if (mode == 1) MRC_SMR_LAUNCH5(short, 1); else MRC_SMR_LAUNCH5(short, 2); }
-        else { if (mode == 1) MRC_SMR_LAUNCH5(double, 1); else MRC_SMR_LAUNCH5(double, 2); }
-        return hipGetLastError();
-    }
-#undef MRC_SMR_LAUNCH5
 #ifndef MRC_SMR_SHORT_LEAN                       // 1: short blocks of the hot paths run smr_short_kernel (a wavefront per unit)
 #define MRC_SMR_SHORT_LEAN 1
 #endif

@@ -182,17 +182,6 @@ bool build_shape(const mrc_config& cfg, int a, int b, HostShape* out, std::strin
         *err = "block length must factor into 2s and 3s";
         return false;
     }
-#ifdef MRC_SMR_FFT8
-    // experiment: the H-point FFT of smr_kernel with two radix-8 passes in front (1024 = 8 x 8 x 4 x 4: one pass and one
-    // workgroup barrier fewer than 4^5)
-    if (S.H % 64 == 0 && (S.H & (S.H - 1)) == 0) {
-        int c = 0, n = S.H / 64;
-        S.radH[c++] = 8; S.radH[c++] = 8;
-        while (n % 4 == 0) { S.radH[c++] = 4; n /= 4; }
-        while (n % 2 == 0) { S.radH[c++] = 2; n /= 2; }
-        S.nRadH = c;
-    }
-#endif
     S.nScaleBits = cfg.n_scale_bits;
     S.maxMantBits = (1 << cfg.n_mant_size_bits) > 16 ? 16 : (1 << cfg.n_mant_size_bits);   // codecThem.py:292-293
     S.twoOverN = 2.0 / N;
