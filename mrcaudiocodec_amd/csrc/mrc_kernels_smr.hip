@@ -448,6 +448,168 @@ __device__ __forceinline__ int wave_incl_scan(int v, int /*lane*/) {
     v += dpp_shift_or_zero<0x143, 0xc>(v);              // row_bcast:31 into rows 2 and 3
     return v;
 }
+__device__ __forceinline__ double wave_incl_scan(double v) {
+    v += dpp_shift_or_zero<0x111, 0xf>(v);              // row_shr:1
+    v += dpp_shift_or_zero<0x112, 0xf>(v);              // row_shr:2
+    v += dpp_shift_or_zero<0x114, 0xf>(v);              // row_shr:4
+    v += dpp_shift_or_zero<0x118, 0xf>(v);              // row_shr:8
+    v += dpp_shift_or_zero<0x142, 0xa>(v);              // row_bcast:15 into rows 1 and 3
+    v += dpp_shift_or_zero<0x143, 0xc>(v);              // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+// ---- Slope nodes: the upper-side sum of a whole frame from R prefix sums over the maskers (round 4).
+// U_k = sum_{m < nUp_k} I_m 2^(s_m (zq_k - z_m)), zq_k = z_k - 1/2, is a sum of exponentials in the line's Bark value whose
+// rates s_m differ from masker to masker -- which is why the lower side (one rate for all) is a suffix sum and this side was
+// not.  Interpolating 2^(s d) in the SLOPE at R equispaced nodes sigma_r = sigma_0 - r h (Lagrange weights lambda_r(s_m)) turns
+// it into R sums with one rate each:
+//     U_k ~= sum_r 2^(sigma_r zq_k) Q_r[nUp_k],     Q_r[n] = sum_{m < n} lambda_r(s_m) I_m 2^(-sigma_r z_m),
+// and because the nodes are equispaced, 2^(sigma_r zq) = E0 g^r with E0 = 2^(sigma_0 zq), g = 2^(-h zq): two 2^x and one
+// Horner pass over R prefix sums per LINE (the masker side likewise: 2^(-sigma_0 z_m) and 2^(h z_m)), instead of one 2^x per
+// (masker, line) pair near the line and an order-16 expansion per chunk far from it.  The nodes span the frame's own slope
+// range [min s, max s] plus kNodeMargin spacings on either side (Lagrange interpolation on equispaced nodes is only well
+// behaved away from the ends).  The prefix sums are kept for every nodeC-th masker (nodeC = ceil(P / 64): one row per lane
+// of the wave that builds them -- 65 rows x 18 columns fit where the Bark grid was); the < nodeC maskers between a line's
+// row and its nUp are added as direct pairs.
+// Error, per line (DESIGN.md section 4 has the derivation): interpolation <= psi* sum_{m < nUp} I_m |prod_r (theta_m - r)| / R!
+// with theta_m = (sigma_0 - s_m) / h and psi* = (h R / |sigma_0|)^R e^-R the maximum over the distance of
+// (h d ln2)^R 2^(sigma_0 d) (column R of Q carries the sum); rounding <= K eps E0 sum_{m < nUp} Lambda_m I_m 2^(-sigma_0 z_m),
+// Lambda_m = sum_r |lambda_r| (column R + 1).  A chunk one of whose lines has  bound > kNodeTol x (its total masked
+// intensity)  is evaluated again by the sorted sweep (upper_cold): lines that live on distant loud maskers (beyond a cliff in
+// the spectrum) are where the interpolation is weakest.  Frames whose slope range is too wide for R nodes, with fewer than
+// kNodeMinMaskers or more than kNodeMaxMaskers maskers take the sorted sweep as a whole.
+constexpr int kNodeR = 16;
+constexpr int kNodeMargin = 1;
+constexpr int kNodeCols = kNodeR + 2;
+constexpr double kNodeHMax = 0.22;                   // node spacing, bit per Bark: the frame's slope range <= 13 x 0.22 = 2.86
+constexpr double kNodeHMin = 1e-3;
+constexpr int kNodeMinMaskers = 32;
+constexpr int kNodeMaxMaskers = 325;                 // 4 P (masker table) + 2 (P + 1) (in-band prefix sums) <= 2048 - 96 doubles
+constexpr double kNodeTol = 1e-13;                   // accepted bound on the error of a line's masked intensity (relative)
+constexpr double kNodeRoundEps = 8.0 * 0x1p-53;      // K eps: K = 8 covers the measured rounding (tools/rank_proto2.py: <= 1.1)
+constexpr double kExpMinus16 = 1.1253517471925912e-07;
+static_assert(kNodeR == 16, "psi* below is written for R = 16");
+struct NodeWeights { double c[kNodeR]; };
+constexpr NodeWeights make_node_weights() {          // 1 / prod_{j != r} (r - j) = (-1)^(R-1-r) / (r! (R-1-r)!)
+    NodeWeights w{};
+    for (int r = 0; r < kNodeR; ++r) {
+        double f = 1.0;
+        for (int j = 2; j <= r; ++j) f *= j;
+        for (int j = 2; j <= kNodeR - 1 - r; ++j) f *= j;
+        w.c[r] = (((kNodeR - 1 - r) & 1) ? -1.0 : 1.0) / f;
+    }
+    return w;
+}
+constexpr NodeWeights kNodeW = make_node_weights();
+
+#ifdef MRC_NODE_STATS                            // diagnostics build: how many units / chunks took which evaluation
+__device__ unsigned long long gNodeStats[4];     // units with nodes, units without, chunks by nodes, chunks sent back
+#define MRC_NODE_COUNT(i) do { if (lane == 0) atomicAdd(&gNodeStats[i], 1ull); } while (0)
+#else
+#define MRC_NODE_COUNT(i) do { } while (0)
+#endif
+
+#ifndef MRC_PROFILE_SKIP                         // profiling aid (wrong results): bit mask of sweep parts to leave out,
+#define MRC_PROFILE_SKIP 0                       // 1 far field, 2 direct pairs, 4 partial pairs, 8 chunk tail
+#endif
+#ifndef MRC_DIRECT_UNROLL                        // pairs in flight per lane in the direct loops
+#define MRC_DIRECT_UNROLL 4
+#endif
+
+// Sorted sweep, far field of chunk c: maskers [0, nFar) lie more than 1/2 Bark below EVERY line of the chunk; their sum is
+// evaluated by far_group() for the whole chunk (one group) or its two halves.  The expansion is in (slope - middle slope of
+// the frame) x (distance from the group's centre): the order follows from half the slope range times half the Bark span, so a
+// frame of similar maskers (noise) gets by with a low order even where 64 lines span more than a Bark, and a frame with a loud
+// and a quiet region still qualifies at the top of the spectrum.  false: the chunk takes no far field.
+template <int TAB, bool HAVE_FAR>
+__device__ __forceinline__ bool far_eval(const double* __restrict__ mt, const double* __restrict__ e2tab,
+                                         const double* __restrict__ zbG, int M, int c, int lane, int nFar, double z,
+                                         double slMid, double spreadHalf, double* out) {
+    if (!HAVE_FAR || nFar < kFarMinMaskers || (MRC_PROFILE_SKIP & 1)) return false;
+    // the group geometry is wave-uniform: scalar loads of the chunk's first / middle / last Bark values
+    const int kFirst = c * kWave;
+    const double zFirst = zbG[kFirst], zLast = zbG[min(kFirst + kWave - 1, M - 1)];
+    const double zHalfEnd = zbG[min(kFirst + kWave / 2 - 1, M - 1)], zHalfBeg = zbG[min(kFirst + kWave / 2, M - 1)];
+    double need = spreadHalf * (0.5 * (zLast - zFirst));
+    int nGroups = 1;
+    if (need > kFarLimitMax) {                     // (wave-uniform)
+        need = spreadHalf * (0.5 * fmax(zHalfEnd - zFirst, zLast - zHalfBeg));
+        nGroups = 2;
+    }
+    const int order = need <= kFarLimit8 ? 8 : need <= kFarLimit12 ? 12 :
+                      (MRC_FAR_MAX_ORDER >= 16 && need <= kFarLimit16) ? 16 :
+                      (MRC_FAR_MAX_ORDER >= 20 && need <= kFarLimit20) ? 20 : 0;
+    if (!order) return false;
+    const int myGroup = (nGroups == 2) ? (lane >> 5) : 0;
+    double acc = 0.0;
+    for (int g = 0; g < nGroups; ++g) {
+        const double cg = (nGroups == 1) ? 0.5 * (zFirst + zLast)
+                                         : (g == 0 ? 0.5 * (zFirst + zHalfEnd) : 0.5 * (zHalfBeg + zLast));
+        const double cq = cg - 0.5, d = z - cg;
+        double p;
+        if (order == 8) p = far_group<8, 9, TAB>(mt, nFar, cq, slMid, d, lane, e2tab);
+        else if (order == 12) p = far_group<12, 16, TAB>(mt, nFar, cq, slMid, d, lane, e2tab);
+#if MRC_FAR_MAX_ORDER >= 20
+        else if (order == 20) p = far_group<20, 24, TAB>(mt, nFar, cq, slMid, d, lane, e2tab);
+#endif
+#if MRC_FAR_MAX_ORDER >= 16
+        else if (order == 16) p = far_group<16, 17, TAB>(mt, nFar, cq, slMid, d, lane, e2tab);
+#endif
+        else p = 0.0;
+        if (g == myGroup) acc = p;
+    }
+    *out = acc;
+    return true;
+}
+
+// Sorted sweep, near field of a chunk: the maskers [mFirst, max nUp) one 2^x per (masker, line) pair, added to tot.  Lines the
+// masker is not below (u = 0) get exactly I_m when they see it at all (m < cnt): the in-band sum of the chunk's tail then
+// starts at max nUp.
+template <int TAB>
+__device__ __forceinline__ double near_eval(const double* __restrict__ mt, const double* __restrict__ e2tab, int nUp,
+                                            int cnt, double zq, bool tookFar, double tot) {
+    // both counts are non-decreasing in the line index: the chunk's bounds sit in its first and last lane
+    const int mLow = __builtin_amdgcn_readfirstlane(cnt);                      // min cnt
+    const int mExp = __builtin_amdgcn_readlane(nUp, kWave - 1);                // max nUp
+    const int mPlain = min(mExp, mLow);
+    const int mFirst = tookFar ? __builtin_amdgcn_readfirstlane(nUp) : 0;
+    // some line of the chunk is above the masker's band, every line sees the masker.  Maskers below
+    // nUp of the chunk's FIRST line are more than 1/2 Bark below every line: u > 0 without the clamp.
+    {
+        const int mPos = min(max(__builtin_amdgcn_readfirstlane(nUp), mFirst), mPlain);
+        const int mStop = (MRC_PROFILE_SKIP & 2) ? 0 : mPlain;
+#pragma unroll MRC_DIRECT_UNROLL
+        for (int m = mFirst; m < min(mPos, mStop); ++m) {
+            const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
+            tot = fma(I, exp2_tab64<TAB>(sl, zq - zm, e2tab), tot);
+        }
+#pragma unroll MRC_DIRECT_UNROLL
+        for (int m = mPos; m < mStop; ++m) {
+            const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
+            const double u = fmax(zq - zm, 0.0);
+            tot = fma(I, exp2_tab64<TAB>(sl, u, e2tab), tot);
+        }
+    }
+    // same, but part of the chunk lies below the masker's band (only when the chunk spans > 1 Bark)
+    for (int m = mPlain; m < ((MRC_PROFILE_SKIP & 4) ? 0 : mExp); ++m) {
+        const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
+        const double u = fmax(zq - zm, 0.0);
+        tot = fma(m < cnt ? I : 0.0, exp2_tab64<TAB>(sl, u, e2tab), tot);
+    }
+    return tot;
+}
+
+// The sorted sweep's upper side for ONE chunk, out of line: where the slope-node evaluation sends a chunk back (rare)
+template <int TAB>
+__device__ __attribute__((noinline)) double upper_cold(const double* mt, const double* e2tab, const double* zbG, int M, int c,
+                                                       int lane, int nUp, int cnt, double z, double slMid,
+                                                       double spreadHalf) {
+    double far = 0.0;
+    const bool took = far_eval<TAB, true>(mt, e2tab, zbG, M, c, lane, __builtin_amdgcn_readfirstlane(nUp), z, slMid,
+                                          spreadHalf, &far);
+    return near_eval<TAB>(mt, e2tab, nUp, cnt, z - 0.5, took, took ? far : 0.0);
+}
+
 
 #ifdef MRC_PROFILE_PHASES
 // profiling build only (make EXTRA=-DMRC_PROFILE_PHASES): shader-clock cycles per kernel phase, summed over waves
@@ -488,12 +650,6 @@ __device__ unsigned long long gPhaseCycles[16];
 #endif
 #ifndef MRC_FAR_PRIO                             // ... and during the far-field pass (shuffle-heavy reductions)
 #define MRC_FAR_PRIO 0
-#endif
-#ifndef MRC_DIRECT_UNROLL                        // pairs in flight per lane in the direct loops
-#define MRC_DIRECT_UNROLL 4
-#endif
-#ifndef MRC_PROFILE_SKIP                         // profiling aid (wrong results): bit mask of sweep parts to leave out,
-#define MRC_PROFILE_SKIP 0                       // 1 far field, 2 direct pairs, 4 partial pairs, 8 chunk tail
 #endif
 
 // DIM: 1024 = the long block (N = 2048: H = M = 1024, 924 bins searched for peaks), 128 = the short block (N = 256: H = M =
@@ -615,6 +771,8 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     // then): the loads complete under the FFT's barriers instead of adding a memory round trip of their own.
     double2 wnPre[kPre];
     double zbPre[kPre], logPre = 0.0, e2Pre = 0.0;
+    [[maybe_unused]] double e2Pre64 = 0.0;              // long blocks: the 64-entry table too (the node terms are built while
+                                                        // the 256-entry one is being staged)
 #pragma unroll
     for (int u = 0; u < kPre; ++u) {
         wnPre[u] = S.wN[min(tid + u * NT, last - 1)];
@@ -623,6 +781,7 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     if (!EXACT) {
         logPre = kLogTabDev.v[tid & (kLogTabEntries * 4 - 1)];
         e2Pre = TAB == kExpTab ? kExp2Tab[tid & (kExpTab - 1)] : kExp2Tab256[tid & 255];
+        if (TAB != kExpTab) e2Pre64 = kExp2Tab[tid & (kExpTab - 1)];
     }
     double2* T;
     if (lay.twOff >= 0) {
@@ -674,7 +833,7 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
             for (int k = tid + kPre * NT; k < M; k += NT) zw[k] = S.zb[k];
         }
         if (tid < kLogTabEntries * 4) smem[lay.logOff + tid] = logPre;
-        if (TAB == kExpTab && tid < kExpTab) smem[2 * H - kExpTab + tid] = e2Pre;
+        if (tid < kExpTab) smem[2 * H - kExpTab + tid] = TAB == kExpTab ? e2Pre : e2Pre64;
         if (tid < kMaxBands) ratioKey[tid] = 0ull;
     }
 
@@ -818,9 +977,33 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         // suffix sums of the lower-side constants: sc[m] = sum_{j >= m} I_j 2^(b z_j), sc[nPeaks] = 0
         double* sc = xi;                                 // xi is dead (all peak reads happened before the barrier)
         if (TAB != kExpTab) smem[4 * H + kTabLongOff + tid] = e2Pre;      // (NT = 256 = TAB: an entry per thread)
-        // four independent scans, dealt to the workgroup's waves (4 waves: one each; 2 waves: two each)
-        for (int task = wave; task < 4; task += NT / kWave) {
-        if (task == 0) {
+        const int waveU = __builtin_amdgcn_readfirstlane(wave);          // (uniform: chunk indices stay in SGPRs)
+        // ---- which evaluation of the upper-side sum the frame takes (wave-uniform): slope nodes (see kNodeR) when its
+        // maskers are many and their slopes lie within reach of R nodes, else the sorted sweep.  Long blocks only.
+        constexpr bool kNodes = LONG && NT == 256;
+        static_assert(!kNodes || (smr_layout(1024, 1024, 924, nullptr).zbOff + (kWave + 1) * kNodeCols <=
+                                  smr_layout(1024, 1024, 924, nullptr).logOff),
+                      "node rows do not fit between the per-line counts and the log10 table");
+        [[maybe_unused]] double nodeH = 0.0, nodeS0 = 0.0;               // node spacing / shallowest node (1/TAB bit per Bark)
+        [[maybe_unused]] int nodeC = 1;                                  // maskers per row of the prefix sums
+        bool useNodes = false;
+        if constexpr (kNodes) {
+            const double lo = order_value(slopeKey[0]), hi = order_value(slopeKey[1]);
+            nodeH = fmax((hi - lo) * (1.0 / (kNodeR - 1 - 2 * kNodeMargin)), kNodeHMin * TAB);
+            nodeS0 = hi + kNodeMargin * nodeH;
+            nodeC = (nPeaks + kWave - 1) / kWave;
+            useNodes = nPeaks >= kNodeMinMaskers && nPeaks <= kNodeMaxMaskers && nodeH <= kNodeHMax * TAB;
+#ifdef MRC_NODES_OFF
+            useNodes = false;
+#endif
+        }
+        // with nodes their rows take the place of the in-band prefix sums (and of the Bark grid before them), which move
+        // behind the masker table
+        double* const nodeQ = piHi;                      // [kWave + 1][kNodeCols]
+        double* piH = piHi;
+        double* piL = piLo;
+        if (kNodes && useNodes) { piH = mt + 4 * nPeaks; piL = piH + (nPeaks + 1); }
+        auto scan_sc = [&]() {
             // kWave * kSeg >= the block's maximum number of peaks + 1: 512 >= N/4 in general; a block of DIM lines has at
             // most (DIM - 101) / 2 (13 for the short block: one per lane; 237 for the transition blocks: four)
             constexpr int kSeg = DIM == 128 ? 1 : DIM == 576 ? 4 : 8;
@@ -833,13 +1016,7 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 run += (m < nPeaks) ? mt[4 * m + 3] : 0.0;
                 loc[i] = run;
             }
-            double incl = run;                          // inclusive prefix over lanes of the segment totals
-            incl += dpp_shift_or_zero<0x111, 0xf>(incl);
-            incl += dpp_shift_or_zero<0x112, 0xf>(incl);
-            incl += dpp_shift_or_zero<0x114, 0xf>(incl);
-            incl += dpp_shift_or_zero<0x118, 0xf>(incl);
-            incl += dpp_shift_or_zero<0x142, 0xa>(incl);
-            incl += dpp_shift_or_zero<0x143, 0xc>(incl);
+            const double incl = wave_incl_scan(run);    // inclusive prefix over lanes of the segment totals
             const double higher = dpp_shift_or_zero<0x138, 0xf>(incl);      // wave_shr:1 -> exclusive: the higher segments
 #pragma unroll
             for (int i = 0; i < kSeg; ++i) {
@@ -847,7 +1024,8 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 if (m < nPeaks) sc[m] = loc[i] + higher;
             }
             if (lane == 0) sc[nPeaks] = 0.0;
-        } else if (task == 1) {
+        };
+        auto scan_pi = [&]() {
             // pi[m] = I_0 + ... + I_{m-1} in double-double: the in-band sum of a line is a DIFFERENCE of two
             // prefix sums, and with ~106 bits the difference is exact to far below one ulp of the result even
             // when a loud masker sits in the prefix (dynamic range of I within a frame < 2^50)
@@ -872,15 +1050,13 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 if (m <= nPeaks) {
                     double h = exH, l = exL;
                     dd_add(&h, &l, locH[i], locL[i]);
-                    piHi[m] = h; piLo[m] = l;
+                    piH[m] = h; piL[m] = l;
                 }
             }
-        }
-        else {
-            // waves 2 and 3 -- per-line masker counts: inclusive prefix sums of the two histograms the table build left
-            // (cnt[k] = maskers with fl(z_k - z_m) >= -1/2, nUp[k] = maskers with fl(z_k - z_m) > 1/2), one array per
-            // wave, so the three scans of this phase run side by side and share one barrier
-            unsigned short* arr = (task == 2) ? cntArr : nUpArr;
+        };
+        auto scan_counts = [&](unsigned short* arr) {
+            // per-line masker counts: inclusive prefix sums of the two histograms the table build left
+            // (cnt[k] = maskers with fl(z_k - z_m) >= -1/2, nUp[k] = maskers with fl(z_k - z_m) > 1/2)
             const int per2 = (M + kWave) / kWave;                            // entries per lane, covers 0..M
             const int k0 = lane * per2, k1 = min(k0 + per2, M + 1);
             int sum = 0;
@@ -890,7 +1066,61 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 run += arr[k];
                 arr[k] = (unsigned short)run;
             }
-        }
+        };
+        // The node terms of the frame's maskers and their prefix sums, by ONE wave: lane l owns the maskers
+        // [l nodeC, (l + 1) nodeC), adds their terms column by column, and row l of Q is the sum over the lanes below it.
+        [[maybe_unused]] auto build_nodes = [&]() {
+            const double* tab64 = smem + 2 * H - kExpTab;                // 2^(j/64) (the 256-entry table is being staged)
+            const double invH = 1.0 / nodeH;
+            const double s0q = nodeS0 * ((double)kExpTab / TAB), hq = nodeH * ((double)kExpTab / TAB);   // 1/64 bit per Bark
+            double acc[kNodeCols];
+#pragma unroll
+            for (int j = 0; j < kNodeCols; ++j) acc[j] = 0.0;
+            for (int i = 0; i < nodeC; ++i) {
+                const int m = lane * nodeC + i;
+                const bool valid = m < nPeaks;
+                const int mm = min(m, nPeaks - 1);
+                const double I = valid ? mt[4 * mm] : 0.0, zm = mt[4 * mm + 1], sl = mt[4 * mm + 2];
+                const double theta = (nodeS0 - sl) * invH;              // the masker's slope in node units, [margin, R-1-margin]
+                double suf[kNodeR];                                      // prod_{j > r} (theta - j)
+                suf[kNodeR - 1] = 1.0;
+#pragma unroll
+                for (int r = kNodeR - 2; r >= 0; --r) suf[r] = suf[r + 1] * (theta - (r + 1));
+                const double F0 = I * exp2_tab64<kExpTab>(-s0q, zm, tab64);      // I 2^(-sigma_0 z_m)
+                const double gm = exp2_tab64<kExpTab>(hq, zm, tab64);            // 2^(h z_m)
+                double F = F0, pre = 1.0, lsum = 0.0;
+#pragma unroll
+                for (int r = 0; r < kNodeR; ++r) {
+                    const double lam = (pre * kNodeW.c[r]) * suf[r];    // lambda_r(theta)
+                    acc[r] = fma(lam, F, acc[r]);
+                    lsum += fabs(lam);
+                    F *= gm;
+                    pre *= theta - r;
+                }
+                acc[kNodeR] = fma(I, fabs(pre) * kInvFactorial[kNodeR], acc[kNodeR]);   // |prod_r (theta - r)| / R!
+                acc[kNodeR + 1] = fma(lsum, F0, acc[kNodeR + 1]);
+            }
+#pragma unroll
+            for (int j = 0; j < kNodeCols; ++j) {
+                const double incl = wave_incl_scan(acc[j]);
+                nodeQ[lane * kNodeCols + j] = dpp_shift_or_zero<0x138, 0xf>(incl);   // wave_shr:1: the lanes below
+                if (lane == kWave - 1) nodeQ[kWave * kNodeCols + j] = incl;
+            }
+        };
+        if (kNodes && useNodes) {
+            // the node terms are the long pole (one wave); the other three scans go to the other waves
+            if constexpr (kNodes) {
+                if (waveU == 0) build_nodes();
+                else if (waveU == 1) { scan_sc(); scan_pi(); }
+                else scan_counts(waveU == 2 ? cntArr : nUpArr);
+            }
+        } else {
+            // four independent scans, dealt to the workgroup's waves (4 waves: one each; 2 waves: two each)
+            for (int task = waveU; task < 4; task += NT / kWave) {
+                if (task == 0) scan_sc();
+                else if (task == 1) scan_pi();
+                else scan_counts(task == 2 ? cntArr : nUpArr);
+            }
         }
         __syncthreads();
         MRC_PHASE(5); MRC_STOP(5);
@@ -899,162 +1129,37 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         // expensive (high) chunks so the four waves finish together.  Per line, the Bark-sorted maskers
         // split into [0, nUp): more than 1/2 Bark below the line (upper slope, needs 2^x),
         // [nUp, cnt): within +-1/2 Bark (contributes exactly I_m), [cnt, P): more than 1/2 Bark above
-        // (lower slope, served by the suffix sums).  Wave-uniform bounds over the chunk turn that into
-        // three scalar loops.
+        // (lower slope, served by the suffix sums).
         const int nChunks = (M + kWave - 1) / kWave;
         const int nWaves = NT / kWave;
         // the per-line constants of the NEXT chunk are loaded while this one is computed (loop-carried, so the
         // global-load latency is never exposed between the loops of a chunk)
         struct LineConst { double z, quiet, lowE, x; int bnd; };
-        const int waveU = __builtin_amdgcn_readfirstlane(wave);          // (uniform: chunk indices stay in SGPRs)
         auto chunk_of = [&](int i) { return i * nWaves + ((i & 1) ? (nWaves - 1 - waveU) : waveU); };
         auto load_consts = [&](int i) {
             const int kc = min(chunk_of(i) * kWave + lane, M - 1);
             return LineConst{S.zb[kc], S.quiet[kc], S.lowE[kc], X[kc], S.bandOfLine[kc]};
         };
-        __builtin_amdgcn_s_setprio(0);
-        const double slMid = 0.5 * (order_value(slopeKey[0]) + order_value(slopeKey[1]));
-        const double spreadHalf = 0.5 * (order_value(slopeKey[1]) - order_value(slopeKey[0])) * (0.6931471805599453094 / TAB);
-        // Rounds of up to four chunks per wave.  Pass 1 evaluates the FAR FIELD of the round's chunks -- the only part
-        // that needs a large register tile (the expansion coefficients) -- and keeps one value per line; pass 2 does
-        // the near maskers, the in-band and lower-side sums and the SPL conversions with that value added in.
-#if defined(MRC_PROFILE_NOSWEEP)                  // profiling aids (wrong results): no unit / units with (unit & n) skip the sweep
-        const bool sweepOn = false;
-#elif defined(MRC_PROFILE_HALFSWEEP)
-        const bool sweepOn = !(unit & MRC_PROFILE_HALFSWEEP);
-#else
-        const bool sweepOn = true;
-#endif
-        for (int i0 = 0; sweepOn && chunk_of(i0) < nChunks; i0 += 4) {
-        // ---- pass 1: far field.  Maskers [0, nFar) lie more than 1/2 Bark below EVERY line of the chunk; their sum is
-        // evaluated by far_group() for the whole chunk (one group) or its two halves.  The expansion is in
-        // (slope - middle slope of the frame) x (distance from the group's centre): the order follows from
-        // half the slope range times half the Bark span, so a frame of similar maskers (noise) gets by with a low
-        // order even where 64 lines span more than a Bark, and a frame with a loud and a quiet region still
-        // qualifies at the top of the spectrum.  The truncated tail is < 1e-17 of each term.
-        __builtin_amdgcn_s_setprio(MRC_FAR_PRIO);
-        double far0 = 0.0, far1 = 0.0, far2 = 0.0, far3 = 0.0;
-        unsigned farMask = 0;                            // bit u: chunk u of the round took the far field
-        // (a block of DIM lines has at most (DIM - 101) / 2 maskers: a short block's 13 never reach kFarMinMaskers, so its
-        // instance carries no far-field code -- and fits the registers of eight waves per SIMD)
-        constexpr bool kHaveFar = DIM == 0 || (DIM - 101) / 2 >= kFarMinMaskers;
-        for (int u = 0; kHaveFar && u < 4; ++u) {
-            const int c = chunk_of(i0 + u);
-            if (c >= nChunks) break;
-            const int kc = min(c * kWave + lane, M - 1);
-            if (haveSwitch && !__any(needBand[S.bandOfLine[kc]])) continue;                      // (see needBand)
-            const int nFar = __builtin_amdgcn_readfirstlane((int)nUpArr[kc]);      // nUp of the chunk's first line
-            if (nFar < kFarMinMaskers || (MRC_PROFILE_SKIP & 1)) continue;
-            const double z = S.zb[kc];
-            // the group geometry is wave-uniform: scalar loads of the chunk's first / middle / last Bark values
-            const int kFirst = c * kWave;
-            const double zFirst = S.zb[kFirst], zLast = S.zb[min(kFirst + kWave - 1, M - 1)];
-            const double zHalfEnd = S.zb[min(kFirst + kWave / 2 - 1, M - 1)], zHalfBeg = S.zb[min(kFirst + kWave / 2, M - 1)];
-            double need = spreadHalf * (0.5 * (zLast - zFirst));
-            int nGroups = 1;
-            if (need > kFarLimitMax) {                     // (wave-uniform)
-                need = spreadHalf * (0.5 * fmax(zHalfEnd - zFirst, zLast - zHalfBeg));
-                nGroups = 2;
-            }
-            const int order = need <= kFarLimit8 ? 8 : need <= kFarLimit12 ? 12 :
-                              (MRC_FAR_MAX_ORDER >= 16 && need <= kFarLimit16) ? 16 :
-                              (MRC_FAR_MAX_ORDER >= 20 && need <= kFarLimit20) ? 20 : 0;
-            if (!order) continue;
-            const int myGroup = (nGroups == 2) ? (lane >> 5) : 0;
-            double acc = 0.0;
-            for (int g = 0; g < nGroups; ++g) {
-                const double cg = (nGroups == 1) ? 0.5 * (zFirst + zLast)
-                                                 : (g == 0 ? 0.5 * (zFirst + zHalfEnd) : 0.5 * (zHalfBeg + zLast));
-                const double cq = cg - 0.5, d = z - cg;
-                double p;
-                if (order == 8) p = far_group<8, 9, TAB>(mt, nFar, cq, slMid, d, lane, e2tab);
-                else if (order == 12) p = far_group<12, 16, TAB>(mt, nFar, cq, slMid, d, lane, e2tab);
-#if MRC_FAR_MAX_ORDER >= 20
-                else if (order == 20) p = far_group<20, 24, TAB>(mt, nFar, cq, slMid, d, lane, e2tab);
-#endif
-#if MRC_FAR_MAX_ORDER >= 16
-                else if (order == 16) p = far_group<16, 17, TAB>(mt, nFar, cq, slMid, d, lane, e2tab);
-#endif
-                else p = 0.0;
-                if (g == myGroup) acc = p;
-            }
-            farMask |= 1u << u;
-            far0 = u == 0 ? acc : far0;
-            far1 = u == 1 ? acc : far1;
-            far2 = u == 2 ? acc : far2;
-            far3 = u == 3 ? acc : far3;
-        }
-        MRC_PHASE(7);
-        // ---- pass 2.  The per-line constants of the NEXT chunk are loaded while this one is computed (loop-carried,
-        // so the global-load latency is never exposed between the loops of a chunk)
-        __builtin_amdgcn_s_setprio(0);
-        LineConst nxt = load_consts(i0);
-        for (int u = 0; u < 4; ++u) {
-            const int i = i0 + u;
-            const int c = chunk_of(i);
-            if (c >= nChunks) break;
-            const int k = c * kWave + lane;
-            const int kc = min(k, M - 1);
-            const LineConst cur = nxt;
-            nxt = load_consts(i + 1);
-            if (haveSwitch && !__any(needBand[cur.bnd])) continue;                               // (see needBand)
-            const double z = cur.z;
-            // quiet threshold + far field (psychoac.py:155,166-168; the order of the additions is free, see above)
-            double tot = cur.quiet + (u == 0 ? far0 : u == 1 ? far1 : u == 2 ? far2 : far3);
-            const int cnt = cntArr[kc], nUp = nUpArr[kc];      // maskers that reach the line / lie > 1/2 Bark below it
-            // both counts are non-decreasing in the line index: the chunk's bounds sit in its first and last lane
-            const int mLow = __builtin_amdgcn_readfirstlane(cnt);                      // min cnt
-            const int mExp = __builtin_amdgcn_readlane(nUp, kWave - 1);                // max nUp
-            const int mPlain = min(mExp, mLow);
-            const double zq = z - 0.5;                 // u = max(z - z_m - 1/2, 0), one subtraction per pair
-            const int mFirst = ((farMask >> u) & 1u) ? __builtin_amdgcn_readfirstlane(nUp) : 0;
-            MRC_PHASE(6);
-            // some line of the chunk is above the masker's band, every line sees the masker.  Maskers below
-            // nUp of the chunk's FIRST line are more than 1/2 Bark below every line: u > 0 without the clamp.
-            {
-                const int mPos = min(max(__builtin_amdgcn_readfirstlane(nUp), mFirst), mPlain);
-                const int mStop = (MRC_PROFILE_SKIP & 2) ? 0 : mPlain;
-#pragma unroll MRC_DIRECT_UNROLL
-                for (int m = mFirst; m < min(mPos, mStop); ++m) {
-                    const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
-                    tot = fma(I, exp2_tab64<TAB>(sl, zq - zm, e2tab), tot);
-                }
-#pragma unroll MRC_DIRECT_UNROLL
-                for (int m = mPos; m < mStop; ++m) {
-                    const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
-                    const double u = fmax(zq - zm, 0.0);
-                    tot = fma(I, exp2_tab64<TAB>(sl, u, e2tab), tot);
-                }
-            }
-            MRC_PHASE(8);
-            // same, but part of the chunk lies below the masker's band (only when the chunk spans > 1 Bark)
-            for (int m = mPlain; m < ((MRC_PROFILE_SKIP & 4) ? 0 : mExp); ++m) {
-                const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
-                const double u = fmax(zq - zm, 0.0);
-                tot = fma(m < cnt ? I : 0.0, exp2_tab64<TAB>(sl, u, e2tab), tot);
-            }
-            MRC_PHASE(9);
-            // no line of the chunk is above the band: every line that sees the masker is inside +-1/2 Bark
-            if (MRC_PROFILE_SKIP & 8) {
-                if (tot + cur.lowE + cur.x == 12345.0 && cur.bnd == 77) bandKey[0] = 1;      // keep the loads alive
-                continue;
-            }
-            if (cnt > mExp) {
-                // sum of I_m over [mExp, cnt) = pi[cnt] - pi[mExp], in double-double
-                const double ah = piHi[cnt], al = piLo[cnt], bh = piHi[mExp], bl = piLo[mExp];
+        // in-band maskers [from, cnt) and the lower side on top of `tot` (quiet threshold + upper side): the line's masked intensity
+        auto tail_sum = [&](double tot, int cnt, int from, double lowE) {
+            if (cnt > from) {
+                // sum of I_m over [from, cnt) = pi[cnt] - pi[from], in double-double
+                const double ah = piH[cnt], al = piL[cnt], bh = piH[from], bl = piL[from];
                 const double d1 = ah - bh;
                 const double v = d1 - ah;
                 const double e = ((ah - (d1 - v)) - (bh + v)) + (al - bl);
                 tot += d1 + e;
             }
             // maskers more than 1/2 Bark above the line: -27 dB/Bark for all of them
-            const double t = fma(cur.lowE, sc[cnt], tot);
-            // psychoac.py:173,212-217: SMR of a band = max over its lines of SPL(4 xs^2) - 6 scale - SPL(t).  Unless one
-            // of the two SPLs sits on its -30 dB floor (digital silence) that is 10 log10(4 xs^2 / t) - 6 scale, and
-            // log10 is monotone: the band maximum of the RATIO is taken and converted once per band at the end
-            // instead of two log10 per line (the difference to the reference's order of roundings is ~1e-14 dB, five
-            // orders below what the FFT in front of it already differs by).  Lines on the floor, and every line when
-            // the caller wants the thresholds themselves, take the reference's formula.
+            return fma(lowE, sc[cnt], tot);
+        };
+        // psychoac.py:173,212-217: SMR of a band = max over its lines of SPL(4 xs^2) - 6 scale - SPL(t).  Unless one
+        // of the two SPLs sits on its -30 dB floor (digital silence) that is 10 log10(4 xs^2 / t) - 6 scale, and
+        // log10 is monotone: the band maximum of the RATIO is taken and converted once per band at the end
+        // instead of two log10 per line (the difference to the reference's order of roundings is ~1e-14 dB, five
+        // orders below what the FFT in front of it already differs by).  Lines on the floor, and every line when
+        // the caller wants the thresholds themselves, take the reference's formula.
+        auto finish = [&](const LineConst& cur, int k, double t) {
             const double xs = ldexp(cur.x, scale);                           // codecThem.py:323 (exact)
             const double a2 = 2. * (xs * xs) / (1. / 2.);
             const bool plain = thresh != nullptr || !(a2 >= kSplFloorGuard && t >= kSplFloorGuard);
@@ -1083,7 +1188,118 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 if (plain) atomicMax(&bandKey[bnd], order_key(ex));
                 if (wantPeak) atomicMax(&peakKey[bnd], (unsigned long long)__double_as_longlong(fabs(cur.x)));
             }
+        };
+        __builtin_amdgcn_s_setprio(0);
+        const double slMid = 0.5 * (order_value(slopeKey[0]) + order_value(slopeKey[1]));
+        const double spreadHalf = 0.5 * (order_value(slopeKey[1]) - order_value(slopeKey[0])) * (0.6931471805599453094 / TAB);
+#if defined(MRC_PROFILE_NOSWEEP)                  // profiling aids (wrong results): no unit / units with (unit & n) skip the sweep
+        const bool sweepOn = false;
+#elif defined(MRC_PROFILE_HALFSWEEP)
+        const bool sweepOn = !(unit & MRC_PROFILE_HALFSWEEP);
+#else
+        const bool sweepOn = true;
+#endif
+        if (kNodes && useNodes) {
+            if constexpr (kNodes) {
+            // ---- slope nodes: per line two 2^x, a Horner pass over its row of prefix sums, and the direct pairs of the
+            // maskers between the row and nUp
+            MRC_NODE_COUNT(0);
+            const int cRecip = 65536 / nodeC + 1;        // n / nodeC = (n cRecip) >> 16 for n < 4096, nodeC <= 8
+            const double xr = (nodeH * kNodeR) / (-nodeS0);
+            double ps = xr * xr;
+            ps *= ps; ps *= ps; ps *= ps;                // (h R / |sigma_0|)^16
+            const double psiStar = ps * kExpMinus16;
+            LineConst nxt = load_consts(0);
+            for (int i = 0; sweepOn && chunk_of(i) < nChunks; ++i) {
+                const int c = chunk_of(i);
+                const int k = c * kWave + lane;
+                const int kc = min(k, M - 1);
+                const LineConst cur = nxt;
+                nxt = load_consts(i + 1);
+                if (haveSwitch && !__any(needBand[cur.bnd])) continue;                           // (see needBand)
+                const int cnt = cntArr[kc], nUp = nUpArr[kc];      // maskers that reach the line / lie > 1/2 Bark below it
+                const double zq = cur.z - 0.5;
+                const int q = (nUp * cRecip) >> 16;
+                const int rem = nUp - q * nodeC;
+                const double* row = nodeQ + q * kNodeCols;
+                const double E0 = exp2_tab64<TAB>(nodeS0, zq, e2tab);
+                const double g = exp2_tab64<TAB>(-nodeH, zq, e2tab);
+                double a = row[kNodeR - 1];
+#pragma unroll
+                for (int r = kNodeR - 2; r >= 0; --r) a = fma(a, g, row[r]);
+                double up = a * E0;
+                const double errBound = fma(psiStar, row[kNodeR], (kNodeRoundEps * E0) * row[kNodeR + 1]);
+                for (int j = 0; j < nodeC - 1; ++j) {
+                    if (!__any(j < rem)) break;
+                    const int m = min(q * nodeC + j, nPeaks - 1);
+                    const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
+                    up = fma(j < rem ? I : 0.0, exp2_tab64<TAB>(sl, zq - zm, e2tab), up);
+                }
+                double t = tail_sum(cur.quiet + up, cnt, nUp, cur.lowE);
+                if (__any(!(errBound <= kNodeTol * t))) {
+                    // a line of this chunk lives on what the interpolation does worst: the chunk goes back to the sorted sweep
+                    MRC_NODE_COUNT(3);
+                    const double tot = cur.quiet + upper_cold<TAB>(mt, e2tab, S.zb, M, c, lane, nUp, cnt, cur.z, slMid, spreadHalf);
+                    t = tail_sum(tot, cnt, __builtin_amdgcn_readlane(nUp, kWave - 1), cur.lowE);
+                } else {
+                    MRC_NODE_COUNT(2);
+                }
+                finish(cur, k, t);
+            }
+            }
+        } else {
+        // ---- sorted sweep.  Rounds of up to four chunks per wave.  Pass 1 evaluates the FAR FIELD of the round's chunks --
+        // the only part that needs a large register tile (the expansion coefficients) -- and keeps one value per line; pass 2
+        // does the near maskers, the in-band and lower-side sums and the SPL conversions with that value added in.
+        MRC_NODE_COUNT(1);
+        for (int i0 = 0; sweepOn && chunk_of(i0) < nChunks; i0 += 4) {
+        __builtin_amdgcn_s_setprio(MRC_FAR_PRIO);
+        double far0 = 0.0, far1 = 0.0, far2 = 0.0, far3 = 0.0;
+        unsigned farMask = 0;                            // bit u: chunk u of the round took the far field
+        // (a block of DIM lines has at most (DIM - 101) / 2 maskers: a short block's 13 never reach kFarMinMaskers, so its
+        // instance carries no far-field code -- and fits the registers of eight waves per SIMD)
+        constexpr bool kHaveFar = DIM == 0 || (DIM - 101) / 2 >= kFarMinMaskers;
+        for (int u = 0; kHaveFar && u < 4; ++u) {
+            const int c = chunk_of(i0 + u);
+            if (c >= nChunks) break;
+            const int kc = min(c * kWave + lane, M - 1);
+            if (haveSwitch && !__any(needBand[S.bandOfLine[kc]])) continue;                      // (see needBand)
+            const int nFar = __builtin_amdgcn_readfirstlane((int)nUpArr[kc]);      // nUp of the chunk's first line
+            double acc = 0.0;
+            if (!far_eval<TAB, kHaveFar>(mt, e2tab, S.zb, M, c, lane, nFar, S.zb[kc], slMid, spreadHalf, &acc)) continue;
+            farMask |= 1u << u;
+            far0 = u == 0 ? acc : far0;
+            far1 = u == 1 ? acc : far1;
+            far2 = u == 2 ? acc : far2;
+            far3 = u == 3 ? acc : far3;
+        }
+        MRC_PHASE(7);
+        // ---- pass 2
+        __builtin_amdgcn_s_setprio(0);
+        LineConst nxt = load_consts(i0);
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u;
+            const int c = chunk_of(i);
+            if (c >= nChunks) break;
+            const int k = c * kWave + lane;
+            const int kc = min(k, M - 1);
+            const LineConst cur = nxt;
+            nxt = load_consts(i + 1);
+            if (haveSwitch && !__any(needBand[cur.bnd])) continue;                               // (see needBand)
+            // quiet threshold + far field (psychoac.py:155,166-168; the order of the additions is free, see above)
+            double tot = cur.quiet + (u == 0 ? far0 : u == 1 ? far1 : u == 2 ? far2 : far3);
+            const int cnt = cntArr[kc], nUp = nUpArr[kc];      // maskers that reach the line / lie > 1/2 Bark below it
+            MRC_PHASE(6);
+            tot = near_eval<TAB>(mt, e2tab, nUp, cnt, cur.z - 0.5, ((farMask >> u) & 1u) != 0, tot);
+            MRC_PHASE(9);
+            if (MRC_PROFILE_SKIP & 8) {
+                if (tot + cur.lowE + cur.x == 12345.0 && cur.bnd == 77) bandKey[0] = 1;      // keep the loads alive
+                continue;
+            }
+            // no line of the chunk is above the band of the maskers from max nUp on: a line that sees one is inside +-1/2 Bark
+            finish(cur, k, tail_sum(tot, cnt, __builtin_amdgcn_readlane(nUp, kWave - 1), cur.lowE));
             MRC_PHASE(10);
+        }
         }
         }
     }
@@ -1294,6 +1510,18 @@ __global__ __launch_bounds__(kWave * kShortWaves) __attribute__((amdgpu_waves_pe
 }
 
 }  // namespace
+
+#ifdef MRC_NODE_STATS
+extern "C" int mrc_debug_node_stats(unsigned long long* out4, int reset) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out4, HIP_SYMBOL(gNodeStats), sizeof(unsigned long long) * 4);
+    if (e == hipSuccess && reset) {
+        unsigned long long z[4] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(gNodeStats), z, sizeof z);
+    }
+    return e == hipSuccess ? 0 : -1;
+}
+#endif
 
 #ifdef MRC_PROFILE_PHASES
 extern "C" int mrc_debug_phase_cycles(unsigned long long* out16, int reset) {
