@@ -516,6 +516,32 @@ __device__ unsigned long long gNodeStats[4];     // units with nodes, units with
 #define MRC_DIRECT_UNROLL 4
 #endif
 
+// Slope nodes, one line: U = E0 Horner_g(row[0 .. R-1]) + the NREM maskers between the line's row and its nUp as direct pairs
+// (rem <= NREM of them count).  NREM is a template parameter so that the pairs' loads and the row's are all in flight together
+// (a loop with an early exit serialises two dependent LDS round trips per pair).  The Horner pass runs as two chains in g^2.
+template <int NREM, int TAB>
+__device__ __forceinline__ double node_line(const double* __restrict__ row, const double* __restrict__ mt,
+                                            const double* __restrict__ e2tab, int mBase, int rem, int mLast, double zq,
+                                            double E0, double g) {
+    double I[NREM > 0 ? NREM : 1], zm[NREM > 0 ? NREM : 1], sl[NREM > 0 ? NREM : 1];
+#pragma unroll
+    for (int j = 0; j < NREM; ++j) {
+        const int m = min(mBase + j, mLast);
+        I[j] = mt[4 * m]; zm[j] = mt[4 * m + 1]; sl[j] = mt[4 * m + 2];
+    }
+    const double g2 = g * g;
+    double ev = row[kNodeR - 2], od = row[kNodeR - 1];
+#pragma unroll
+    for (int r = kNodeR - 4; r >= 0; r -= 2) {
+        ev = fma(ev, g2, row[r]);
+        od = fma(od, g2, row[r + 1]);
+    }
+    double up = fma(od, g, ev) * E0;
+#pragma unroll
+    for (int j = 0; j < NREM; ++j) up = fma(j < rem ? I[j] : 0.0, exp2_tab64<TAB>(sl[j], zq - zm[j], e2tab), up);
+    return up;
+}
+
 // Sorted sweep, far field of chunk c: maskers [0, nFar) lie more than 1/2 Bark below EVERY line of the chunk; their sum is
 // evaluated by far_group() for the whole chunk (one group) or its two halves.  The expansion is in (slope - middle slope of
 // the frame) x (distance from the group's centre): the order follows from half the slope range times half the Bark span, so a
@@ -1110,7 +1136,11 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         if (kNodes && useNodes) {
             // the node terms are the long pole (one wave); the other three scans go to the other waves
             if constexpr (kNodes) {
+#ifdef MRC_PROFILE_NODESKIP                      // profiling aid (wrong results): 1 no node build, 2 no remainder pairs, 4 no Horner
+                if (waveU == 0 && !(MRC_PROFILE_NODESKIP & 1)) build_nodes();
+#else
                 if (waveU == 0) build_nodes();
+#endif
                 else if (waveU == 1) { scan_sc(); scan_pi(); }
                 else scan_counts(waveU == 2 ? cntArr : nUpArr);
             }
@@ -1219,24 +1249,33 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 if (haveSwitch && !__any(needBand[cur.bnd])) continue;                           // (see needBand)
                 const int cnt = cntArr[kc], nUp = nUpArr[kc];      // maskers that reach the line / lie > 1/2 Bark below it
                 const double zq = cur.z - 0.5;
+                MRC_PHASE(6);
                 const int q = (nUp * cRecip) >> 16;
                 const int rem = nUp - q * nodeC;
                 const double* row = nodeQ + q * kNodeCols;
                 const double E0 = exp2_tab64<TAB>(nodeS0, zq, e2tab);
                 const double g = exp2_tab64<TAB>(-nodeH, zq, e2tab);
-                double a = row[kNodeR - 1];
-#pragma unroll
-                for (int r = kNodeR - 2; r >= 0; --r) a = fma(a, g, row[r]);
-                double up = a * E0;
                 const double errBound = fma(psiStar, row[kNodeR], (kNodeRoundEps * E0) * row[kNodeR + 1]);
-                for (int j = 0; j < nodeC - 1; ++j) {
-                    if (!__any(j < rem)) break;
-                    const int m = min(q * nodeC + j, nPeaks - 1);
-                    const double I = mt[4 * m], zm = mt[4 * m + 1], sl = mt[4 * m + 2];
-                    up = fma(j < rem ? I : 0.0, exp2_tab64<TAB>(sl, zq - zm, e2tab), up);
+                double up;
+                const int mBase = q * nodeC;
+#ifdef MRC_PROFILE_NODESKIP
+                if (MRC_PROFILE_NODESKIP & 2) up = node_line<0, TAB>(row, mt, e2tab, mBase, rem, nPeaks - 1, zq, E0, g); else
+#endif
+                switch (nodeC) {                         // (wave-uniform)
+                    case 1: up = node_line<0, TAB>(row, mt, e2tab, mBase, rem, nPeaks - 1, zq, E0, g); break;
+                    case 2: up = node_line<1, TAB>(row, mt, e2tab, mBase, rem, nPeaks - 1, zq, E0, g); break;
+                    case 3: up = node_line<2, TAB>(row, mt, e2tab, mBase, rem, nPeaks - 1, zq, E0, g); break;
+                    case 4: up = node_line<3, TAB>(row, mt, e2tab, mBase, rem, nPeaks - 1, zq, E0, g); break;
+                    case 5: up = node_line<4, TAB>(row, mt, e2tab, mBase, rem, nPeaks - 1, zq, E0, g); break;
+                    default: up = node_line<5, TAB>(row, mt, e2tab, mBase, rem, nPeaks - 1, zq, E0, g); break;
                 }
+                MRC_PHASE(8);
                 double t = tail_sum(cur.quiet + up, cnt, nUp, cur.lowE);
+#ifdef MRC_PROFILE_NODESKIP
+                if (false) {
+#else
                 if (__any(!(errBound <= kNodeTol * t))) {
+#endif
                     // a line of this chunk lives on what the interpolation does worst: the chunk goes back to the sorted sweep
                     MRC_NODE_COUNT(3);
                     const double tot = cur.quiet + upper_cold<TAB>(mt, e2tab, S.zb, M, c, lane, nUp, cnt, cur.z, slMid, spreadHalf);
@@ -1245,6 +1284,7 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                     MRC_NODE_COUNT(2);
                 }
                 finish(cur, k, t);
+                MRC_PHASE(10);
             }
             }
         } else {
