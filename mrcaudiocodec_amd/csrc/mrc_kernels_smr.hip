@@ -468,9 +468,9 @@ __device__ __forceinline__ double wave_incl_scan(double v) {
 // Horner pass over R prefix sums per LINE (the masker side likewise: 2^(-sigma_0 z_m) and 2^(h z_m)), instead of one 2^x per
 // (masker, line) pair near the line and an order-16 expansion per chunk far from it.  The nodes span the frame's own slope
 // range [min s, max s] plus kNodeMargin spacings on either side (Lagrange interpolation on equispaced nodes is only well
-// behaved away from the ends).  The prefix sums are kept for every nodeC-th masker (nodeC = ceil(P / 64): one row per lane
-// of the wave that builds them -- 65 rows x 18 columns fit where the Bark grid was); the < nodeC maskers between a line's
-// row and its nUp are added as direct pairs.
+// behaved away from the ends).  The prefix sums are kept for every fourth masker (a row per quad of lanes of the waves that
+// compute the terms: <= 78 rows x 18 columns fit where the peak bins and the Bark grid were); the <= 3 maskers between a
+// line's row and its nUp are added as direct pairs.
 // Error, per line (DESIGN.md section 4 has the derivation): interpolation <= psi* sum_{m < nUp} I_m |prod_r (theta_m - r)| / R!
 // with theta_m = (sigma_0 - s_m) / h and psi* = (h R / |sigma_0|)^R e^-R the maximum over the distance of
 // (h d ln2)^R 2^(sigma_0 d) (column R of Q carries the sum); rounding <= K eps E0 sum_{m < nUp} Lambda_m I_m 2^(-sigma_0 z_m),
@@ -484,7 +484,9 @@ constexpr int kNodeCols = kNodeR + 2;
 constexpr double kNodeHMax = 0.22;                   // node spacing, bit per Bark: the frame's slope range <= 13 x 0.22 = 2.86
 constexpr double kNodeHMin = 1e-3;
 constexpr int kNodeMinMaskers = 32;
-constexpr int kNodeMaxMaskers = 325;                 // 4 P (masker table) + 2 (P + 1) (in-band prefix sums) <= 2048 - 96 doubles
+constexpr int kNodeC = 4;                            // maskers per row of the prefix sums (a quad of lanes)
+constexpr int kNodeMaxMaskers = 308;                 // 78 rows fit in front of the log10 table (and 4 P + 2 (P + 1) <= 2048 - 96)
+constexpr int kNodeSeg = 26;                         // rows per lane in the scan over the rows (three lanes per column)
 constexpr double kNodeTol = 1e-13;                   // accepted bound on the error of a line's masked intensity (relative)
 constexpr double kNodeRoundEps = 8.0 * 0x1p-53;      // K eps: K = 8 covers the measured rounding (tools/rank_proto2.py: <= 1.1)
 constexpr double kExpMinus16 = 1.1253517471925912e-07;
@@ -738,10 +740,11 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     double2* B = A + H;                                 // [H]
     double* xi = smem + 4 * H;    // [peakLast + 1] intensity spectrum; later the suffix sums
     // region B is free once the spectrum is in xi: peak bins, then per-line masker counts (filled below)
-    short* pkBin = reinterpret_cast<short*>(smem + 2 * H);              // [<= peakLast/2 + 1] peak bins, increasing
-    unsigned short* cntArr = reinterpret_cast<unsigned short*>(pkBin + ((last / 2 + 5) & ~3));   // [M + 1]
+    unsigned short* cntArr = reinterpret_cast<unsigned short*>(smem + 2 * H);   // [M + 1]
     unsigned short* nUpArr = cntArr + (M + 2);                           // [M + 1]
-    double* piHi = reinterpret_cast<double*>(nUpArr + (M + 2));   // [<= peakLast/2 + 2] prefix sums of
+    short* pkBin = reinterpret_cast<short*>(nUpArr + (M + 2));           // [<= peakLast/2 + 1] peak bins, increasing; dead after
+                                                                         // the masker table (then the start of the node rows)
+    double* piHi = reinterpret_cast<double*>(pkBin + ((last / 2 + 5) & ~3));   // [<= peakLast/2 + 2] prefix sums of
     double* piLo = piHi + (last / 2 + 2);                //   the masker intensities, double-double (hi, lo)
 
 #ifdef MRC_PROFILE_PHASES
@@ -1007,17 +1010,16 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         // ---- which evaluation of the upper-side sum the frame takes (wave-uniform): slope nodes (see kNodeR) when its
         // maskers are many and their slopes lie within reach of R nodes, else the sorted sweep.  Long blocks only.
         constexpr bool kNodes = LONG && NT == 256;
-        static_assert(!kNodes || (smr_layout(1024, 1024, 924, nullptr).zbOff + (kWave + 1) * kNodeCols <=
+        static_assert(!kNodes || (2 * 1024 + (2 * 1026 * 2) / 8 + ((kNodeMaxMaskers + kNodeC - 1) / kNodeC + 1) * kNodeCols <=
                                   smr_layout(1024, 1024, 924, nullptr).logOff),
                       "node rows do not fit between the per-line counts and the log10 table");
+        static_assert(3 * kNodeSeg >= (kNodeMaxMaskers + kNodeC - 1) / kNodeC, "node_scan: three lanes per column cover the rows");
         [[maybe_unused]] double nodeH = 0.0, nodeS0 = 0.0;               // node spacing / shallowest node (1/TAB bit per Bark)
-        [[maybe_unused]] int nodeC = 1;                                  // maskers per row of the prefix sums
         bool useNodes = false;
         if constexpr (kNodes) {
             const double lo = order_value(slopeKey[0]), hi = order_value(slopeKey[1]);
             nodeH = fmax((hi - lo) * (1.0 / (kNodeR - 1 - 2 * kNodeMargin)), kNodeHMin * TAB);
             nodeS0 = hi + kNodeMargin * nodeH;
-            nodeC = (nPeaks + kWave - 1) / kWave;
             useNodes = nPeaks >= kNodeMinMaskers && nPeaks <= kNodeMaxMaskers && nodeH <= kNodeHMax * TAB;
 #ifdef MRC_NODES_OFF
             useNodes = false;
@@ -1025,7 +1027,7 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         }
         // with nodes their rows take the place of the in-band prefix sums (and of the Bark grid before them), which move
         // behind the masker table
-        double* const nodeQ = piHi;                      // [kWave + 1][kNodeCols]
+        double* const nodeQ = reinterpret_cast<double*>(pkBin);   // [<= 78][kNodeCols]: from the (dead) peak bins to the log10 table
         double* piH = piHi;
         double* piL = piLo;
         if (kNodes && useNodes) { piH = mt + 4 * nPeaks; piL = piH + (nPeaks + 1); }
@@ -1093,17 +1095,16 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 arr[k] = (unsigned short)run;
             }
         };
-        // The node terms of the frame's maskers and their prefix sums, by ONE wave: lane l owns the maskers
-        // [l nodeC, (l + 1) nodeC), adds their terms column by column, and row l of Q is the sum over the lanes below it.
-        [[maybe_unused]] auto build_nodes = [&]() {
+        // The node terms, a masker per thread: lambda_r(theta) in product form (prefix x suffix products of theta - j), the two
+        // 2^x, the R terms and the two error-bound terms; the four maskers of a row are lanes 4 j .. 4 j + 3 of a wave and
+        // are summed there (two DPP steps); row j + 1 of Q gets the row's total, to be turned into prefix sums by node_scan.
+        [[maybe_unused]] auto node_terms = [&]() {
             const double* tab64 = smem + 2 * H - kExpTab;                // 2^(j/64) (the 256-entry table is being staged)
             const double invH = 1.0 / nodeH;
             const double s0q = nodeS0 * ((double)kExpTab / TAB), hq = nodeH * ((double)kExpTab / TAB);   // 1/64 bit per Bark
-            double acc[kNodeCols];
-#pragma unroll
-            for (int j = 0; j < kNodeCols; ++j) acc[j] = 0.0;
-            for (int i = 0; i < nodeC; ++i) {
-                const int m = lane * nodeC + i;
+            if (tid < kNodeCols) nodeQ[tid] = 0.0;                       // row 0: no masker below
+            for (int base = waveU * kWave; base < nPeaks; base += NT) {  // (wave-uniform)
+                const int m = base + lane;
                 const bool valid = m < nPeaks;
                 const int mm = min(m, nPeaks - 1);
                 const double I = valid ? mt[4 * mm] : 0.0, zm = mt[4 * mm + 1], sl = mt[4 * mm + 2];
@@ -1114,42 +1115,73 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 for (int r = kNodeR - 2; r >= 0; --r) suf[r] = suf[r + 1] * (theta - (r + 1));
                 const double F0 = I * exp2_tab64<kExpTab>(-s0q, zm, tab64);      // I 2^(-sigma_0 z_m)
                 const double gm = exp2_tab64<kExpTab>(hq, zm, tab64);            // 2^(h z_m)
+                double G[kNodeCols];
                 double F = F0, pre = 1.0, lsum = 0.0;
 #pragma unroll
                 for (int r = 0; r < kNodeR; ++r) {
                     const double lam = (pre * kNodeW.c[r]) * suf[r];    // lambda_r(theta)
-                    acc[r] = fma(lam, F, acc[r]);
+                    G[r] = lam * F;
                     lsum += fabs(lam);
                     F *= gm;
                     pre *= theta - r;
                 }
-                acc[kNodeR] = fma(I, fabs(pre) * kInvFactorial[kNodeR], acc[kNodeR]);   // |prod_r (theta - r)| / R!
-                acc[kNodeR + 1] = fma(lsum, F0, acc[kNodeR + 1]);
-            }
+                G[kNodeR] = I * (fabs(pre) * kInvFactorial[kNodeR]);    // I |prod_r (theta - r)| / R!
+                G[kNodeR + 1] = lsum * F0;
+                const bool store = (lane & 3) == 0 && valid;            // (the row's first masker exists)
+                double* rowOut = nodeQ + ((m >> 2) + 1) * kNodeCols;
 #pragma unroll
-            for (int j = 0; j < kNodeCols; ++j) {
-                const double incl = wave_incl_scan(acc[j]);
-                nodeQ[lane * kNodeCols + j] = dpp_shift_or_zero<0x138, 0xf>(incl);   // wave_shr:1: the lanes below
-                if (lane == kWave - 1) nodeQ[kWave * kNodeCols + j] = incl;
+                for (int j = 0; j < kNodeCols; ++j) {
+                    double v = G[j];
+                    v += dpp_move<0xB1>(v);                              // quad_perm [1,0,3,2]
+                    v += dpp_move<0x4E>(v);                              // quad_perm [2,3,0,1]
+                    if (store) rowOut[j] = v;
+                }
             }
         };
-        if (kNodes && useNodes) {
-            // the node terms are the long pole (one wave); the other three scans go to the other waves
-            if constexpr (kNodes) {
-#ifdef MRC_PROFILE_NODESKIP                      // profiling aid (wrong results): 1 no node build, 2 no remainder pairs, 4 no Horner
-                if (waveU == 0 && !(MRC_PROFILE_NODESKIP & 1)) build_nodes();
-#else
-                if (waveU == 0) build_nodes();
-#endif
-                else if (waveU == 1) { scan_sc(); scan_pi(); }
-                else scan_counts(waveU == 2 ? cntArr : nUpArr);
+        // Row totals -> prefix sums, in place, by one wave: lane = (column, third of the rows); a lane loads its <= 26 rows of the
+        // column at once, sums them up in registers, the three thirds of a column exchange their totals through ds_bpermute.
+        [[maybe_unused]] auto node_scan = [&]() {
+            const int nR = (nPeaks + kNodeC - 1) / kNodeC;               // rows 1 .. nR hold totals; row q becomes sum_{m < 4 q}
+            const int L = (nR + 2) / 3;
+            const int seg = (lane >= kNodeCols ? 1 : 0) + (lane >= 2 * kNodeCols ? 1 : 0) + (lane >= 3 * kNodeCols ? 1 : 0);
+            const int col = lane - seg * kNodeCols;
+            const bool live = seg < 3;
+            double v[kNodeSeg];
+#pragma unroll
+            for (int i = 0; i < kNodeSeg; ++i) {
+                const int r = 1 + seg * L + i;
+                v[i] = (live && i < L && r <= nR) ? nodeQ[r * kNodeCols + col] : 0.0;
             }
-        } else {
-            // four independent scans, dealt to the workgroup's waves (4 waves: one each; 2 waves: two each)
-            for (int task = waveU; task < 4; task += NT / kWave) {
-                if (task == 0) scan_sc();
-                else if (task == 1) scan_pi();
-                else scan_counts(task == 2 ? cntArr : nUpArr);
+#pragma unroll
+            for (int i = 1; i < kNodeSeg; ++i) v[i] += v[i - 1];
+            const double tot = v[kNodeSeg - 1];
+            const int tlo = __double2loint(tot), thi = __double2hiint(tot);
+            const double t0 = __hiloint2double(__builtin_amdgcn_ds_bpermute(4 * col, thi), __builtin_amdgcn_ds_bpermute(4 * col, tlo));
+            const double t1 = __hiloint2double(__builtin_amdgcn_ds_bpermute(4 * (col + kNodeCols), thi),
+                                               __builtin_amdgcn_ds_bpermute(4 * (col + kNodeCols), tlo));
+            const double off = (seg >= 1 ? t0 : 0.0) + (seg >= 2 ? t1 : 0.0);
+#pragma unroll
+            for (int i = 0; i < kNodeSeg; ++i) {
+                const int r = 1 + seg * L + i;
+                if (live && i < L && r <= nR) nodeQ[r * kNodeCols + col] = v[i] + off;
+            }
+        };
+#ifndef MRC_PROFILE_NODESKIP                     // profiling aid (wrong results): 1 no node terms, 2 no remainder pairs, 4 no Horner
+#define MRC_PROFILE_NODESKIP 0
+#endif
+        if constexpr (kNodes) {
+            if (useNodes && !(MRC_PROFILE_NODESKIP & 1)) node_terms();
+        }
+        // four independent scans, dealt to the workgroup's waves (4 waves: one each; 2 waves: two each)
+        for (int task = waveU; task < 4; task += NT / kWave) {
+            if (task == 0) scan_sc();
+            else if (task == 1) scan_pi();
+            else scan_counts(task == 2 ? cntArr : nUpArr);
+        }
+        if constexpr (kNodes) {
+            if (useNodes) {                              // (workgroup-uniform)
+                __syncthreads();
+                if (waveU == 0 && !(MRC_PROFILE_NODESKIP & 1)) node_scan();
             }
         }
         __syncthreads();
@@ -1234,7 +1266,6 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
             // ---- slope nodes: per line two 2^x, a Horner pass over its row of prefix sums, and the direct pairs of the
             // maskers between the row and nUp
             MRC_NODE_COUNT(0);
-            const int cRecip = 65536 / nodeC + 1;        // n / nodeC = (n cRecip) >> 16 for n < 4096, nodeC <= 8
             const double xr = (nodeH * kNodeR) / (-nodeS0);
             double ps = xr * xr;
             ps *= ps; ps *= ps; ps *= ps;                // (h R / |sigma_0|)^16
@@ -1250,32 +1281,16 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 const int cnt = cntArr[kc], nUp = nUpArr[kc];      // maskers that reach the line / lie > 1/2 Bark below it
                 const double zq = cur.z - 0.5;
                 MRC_PHASE(6);
-                const int q = (nUp * cRecip) >> 16;
-                const int rem = nUp - q * nodeC;
+                const int q = nUp >> 2, rem = nUp & 3;   // (kNodeC = 4)
                 const double* row = nodeQ + q * kNodeCols;
                 const double E0 = exp2_tab64<TAB>(nodeS0, zq, e2tab);
                 const double g = exp2_tab64<TAB>(-nodeH, zq, e2tab);
                 const double errBound = fma(psiStar, row[kNodeR], (kNodeRoundEps * E0) * row[kNodeR + 1]);
-                double up;
-                const int mBase = q * nodeC;
-#ifdef MRC_PROFILE_NODESKIP
-                if (MRC_PROFILE_NODESKIP & 2) up = node_line<0, TAB>(row, mt, e2tab, mBase, rem, nPeaks - 1, zq, E0, g); else
-#endif
-                switch (nodeC) {                         // (wave-uniform)
-                    case 1: up = node_line<0, TAB>(row, mt, e2tab, mBase, rem, nPeaks - 1, zq, E0, g); break;
-                    case 2: up = node_line<1, TAB>(row, mt, e2tab, mBase, rem, nPeaks - 1, zq, E0, g); break;
-                    case 3: up = node_line<2, TAB>(row, mt, e2tab, mBase, rem, nPeaks - 1, zq, E0, g); break;
-                    case 4: up = node_line<3, TAB>(row, mt, e2tab, mBase, rem, nPeaks - 1, zq, E0, g); break;
-                    case 5: up = node_line<4, TAB>(row, mt, e2tab, mBase, rem, nPeaks - 1, zq, E0, g); break;
-                    default: up = node_line<5, TAB>(row, mt, e2tab, mBase, rem, nPeaks - 1, zq, E0, g); break;
-                }
+                const double up = (MRC_PROFILE_NODESKIP & 2) ? node_line<0, TAB>(row, mt, e2tab, 4 * q, rem, nPeaks - 1, zq, E0, g)
+                                                             : node_line<kNodeC - 1, TAB>(row, mt, e2tab, 4 * q, rem, nPeaks - 1, zq, E0, g);
                 MRC_PHASE(8);
                 double t = tail_sum(cur.quiet + up, cnt, nUp, cur.lowE);
-#ifdef MRC_PROFILE_NODESKIP
-                if (false) {
-#else
-                if (__any(!(errBound <= kNodeTol * t))) {
-#endif
+                if (!MRC_PROFILE_NODESKIP && __any(!(errBound <= kNodeTol * t))) {
                     // a line of this chunk lives on what the interpolation does worst: the chunk goes back to the sorted sweep
                     MRC_NODE_COUNT(3);
                     const double tot = cur.quiet + upper_cold<TAB>(mt, e2tab, S.zb, M, c, lane, nUp, cnt, cur.z, slMid, spreadHalf);
