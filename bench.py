@@ -564,11 +564,36 @@ def main():
         cfgs["single_stream"] = single_stream_leg(np, torch, enc, device, args.single_hops)
         line["configs"] = cfgs
         del xs, groups
+        # ---- the per-GPU share of configs[4] at its real size, on this one GPU: rank 0's slice of the 8-rank job (frames
+        # [0, 10^7 / 8) of the C3 stream, its halo in front), joint path -- the N = 1 anchor of the N = 8 line below
+        del pcm
+        enc._out.clear()
+        torch.cuda.empty_cache()
+        Fs = args.c4_frames
+        sl, sr = stream_slices(torch, device, "c3", 0, Fs)
+        torch.cuda.reset_peak_memory_stats(device)
+        es = timed_steps(lambda: enc.encode_long(sl, sr, Fs, mantissa16=True))
+        free_b, total_b = torch.cuda.mem_get_info(device)
+        km = kernel_ms(lambda: enc.encode_long(sl, sr, Fs, mantissa16=True), reps=2)
+        line["configs4_share"] = {
+            "workload": "configs[4], one rank's share at its real size: frames [0, %d) of the C3 stereo stream (10^7 / 8), joint "
+                        "path, independent-frames mode, resident int16 PCM -> uint16 codes" % Fs,
+            "value": round(2.0 * Fs * HOP * args.steps / es / 1e6, 3), "unit": "Msamples/s",
+            "frames_per_step": Fs, "ms_per_step": round(es / args.steps * 1e3, 3),
+            "kernel_ms": {n: round(float(v), 3) for n, v in zip(("mdct", "smr", "ms_switch", "bitalloc", "quantize"), km)},
+            "hbm_in_use_GB": round((total_b - free_b) / 1e9, 2),
+            "hbm_in_use_note": "device memory in use after the timed steps (hipMemGetInfo): the library's workspace -- MDCT "
+                               "lines of four signals, SMRs, band peaks -- plus PCM and outputs held by the caller",
+            "torch_peak_allocated_GB": round(torch.cuda.max_memory_allocated(device) / 1e9, 2)}
+        del sl, sr
+        enc._out.clear()
+        torch.cuda.empty_cache()
 
     if world > 1 and not args.skip_extras:
         # ---- configs[4]: the C3 stereo stream, frame-sharded, joint path, host pack reported separately.  10^7 / 8 frames per
         # GPU (~54 GB of HBM: 10^7 frames at N = 8; the same per-GPU share at every N: weak scaling)
         del pcm
+        enc._out.clear()
         torch.cuda.empty_cache()
         Fs = args.c4_frames
         first_s, cnt = shard_frames(world * Fs, world, rank)

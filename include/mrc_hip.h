@@ -201,7 +201,9 @@ int mrc_transient_peaks_ex(mrc_handle* h, int64_t n_hops, int n_channels, int n_
                            const void* streams, int sample_format, double* peaks);
 /* The same on streams that are already in DEVICE memory, as float64 signed fractions or as the file's int16 PCM codes
  * (converted on load, pcmfile.py:91-100): channel c starts at streams + c * channel_stride samples; peaks (device)
- * [n_hops][n_channels][nMDCTLines/nSamplesShort + 1]; sos is a HOST pointer.  Enqueued on `stream`. */
+ * [n_hops][n_channels][nMDCTLines/nSamplesShort + 1]; sos is a HOST pointer.  Enqueued on `stream`.  The filter
+ * coefficients are staged in a buffer the HANDLE owns: one stream per handle at a time -- a second call on another stream
+ * while the first may still run would overwrite (or, growing, free) what its kernel reads; use one handle per stream. */
 int mrc_dev_transient_peaks(mrc_handle* h, int64_t n_hops, int n_channels, int n_sections, const double* sos,
                             const void* streams, int sample_format, int64_t channel_stride, double* peaks, void* stream);
 /* ms_stereo.py:53-67 elementwise over n lines: out_mid = max(mid, min(side, MLD side)), out_side likewise, MLD from z
@@ -387,6 +389,10 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
                                uint8_t* out, int64_t out_cap, int64_t* stream_byte_offset, int64_t* item_byte_offset,
                                int32_t* reservoir_out, int32_t* reservoir_trace, int64_t* total_bytes, void* stream);
 int mrc_get_chain_ms(mrc_handle* h, double* ms /*[4]*/);
+/* mrc_chain_fetch_output: the bytes of the LAST mrc_encode_chained_stream[_pcm16]_pac call on this handle, which stay in the
+ * handle's device buffer until the next chained call: after MRC_ERR_NOMEM ("out_cap too small") a caller allocates
+ * total_bytes and fetches them -- no second encode.  The offsets / reservoirs of that call were already returned by it. */
+int mrc_chain_fetch_output(mrc_handle* h, uint8_t* out, int64_t out_cap, int64_t* total_bytes);
 
 /* ---- decode side ("next" row f-4: the reference's decoder, pacfileThem.py:130-585 + codecThem.py:30-134) ----
  * Host: header and chunk parsing (no GPU, no handle).  Device: dequantise -> undo the overall scale -> M/S

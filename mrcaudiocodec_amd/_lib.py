@@ -144,6 +144,7 @@ def _load():
                                       _i32p, _i32p, _i32p, _u8p, C.c_int64, _i64p, _i32p, _i32p]),
         "mrc_pack_joint_blocks": (C.c_int, [C.POINTER(MrcConfig), C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p,
                                             _i32p, _i32p, _i32p, _u8p, C.c_int64, _i64p, _i32p, _i32p]),
+        "mrc_chain_fetch_output": (C.c_int, [H, C.c_void_p, C.c_int64, _i64p]),
         "mrc_set_timing": (C.c_int, [H, C.c_int]),
         "mrc_set_option": (C.c_int, [H, C.c_int, C.c_int]),
         "mrc_get_option": (C.c_int, [H, C.c_int, _i32p]),
@@ -458,17 +459,17 @@ class Handle:
                                                 1 if with_flush else 0, 0 if ns is None else 1))
             if bound < 0:
                 raise MrcError("mrc_chain_out_bound failed (%d): block shape out of range" % bound)
-            # a first buffer for typical content (~3 bits per sample), the worst case only if that turns out too small
+            # a buffer for typical content (~3 bits per sample); if the streams pack to more, the call says how much and
+            # its bytes -- complete in the handle's device buffer -- are fetched into a buffer of that size (no second encode)
             cap = min(bound, int(off.size) * 1024 + n_streams * 4096 + 4096)
-            for attempt in (0, 1):
-                buf = np.empty(max(cap, 1), np.uint8)
-                rc = lib.mrc_encode_chained_stream_pac(self._h, n_streams, vp(pl), vp(pr), fmt, stride, *sched, vp(buf),
-                                                       buf.size, *tail)
-                if rc == MRC_ERR_NOMEM and attempt == 0 and cap < bound:
-                    cap = bound
-                    continue
+            buf = np.empty(max(cap, 1), np.uint8)
+            rc = lib.mrc_encode_chained_stream_pac(self._h, n_streams, vp(pl), vp(pr), fmt, stride, *sched, vp(buf),
+                                                   buf.size, *tail)
+            if rc == MRC_ERR_NOMEM and 0 < int(total[0]) <= bound:
+                buf = np.empty(int(total[0]), np.uint8)
+                self._check(lib.mrc_chain_fetch_output(self._h, vp(buf), buf.size, total.ctypes.data_as(_i64p)))
+            else:
                 self._check(rc)
-                break
             buf = buf[:int(total[0])]
         out = {"bytes": buf, "stream_offset": s_off, "item_offset": i_off, "reservoir_out": res_out, "total": int(total[0])}
         if want_trace:

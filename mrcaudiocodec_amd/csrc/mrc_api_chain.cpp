@@ -44,10 +44,16 @@ int mrc_get_chain_ms(mrc_handle* h, double* ms) {
 int64_t mrc_chain_out_bound(mrc_handle* h, int64_t n_streams, const int64_t* block_start, const int32_t* block_a,
                             const int32_t* block_b, int with_flush, int with_headers) {
     if (!h || n_streams < 0 || !block_start || !block_a || !block_b) return MRC_ERR_INVALID;
-    const int L = h->cfg.n_mdct_lines;
+    const int L = h->cfg.n_mdct_lines, Sh = h->cfg.n_short;
+    // a stream has four block shapes: their bounds once, not one band table per block
+    const int sa[4] = {L, L, Sh, Sh}, sb[4] = {L, Sh, Sh, L};
+    int64_t shapeBound[4];
+    for (int g = 0; g < 4; ++g) shapeBound[g] = mrc_pack_bound(&h->cfg, sa[g], sb[g], 2, 1);
     int64_t total = 0;
     for (int64_t i = block_start[0]; i < block_start[n_streams]; ++i) {
-        const int64_t bnd = mrc_pack_bound(&h->cfg, block_a[i], block_b[i], 2, 1);
+        const int g = (block_a[i] == L ? 0 : 2) + ((block_a[i] == L) == (block_b[i] == L) ? 0 : 1);
+        int64_t bnd = shapeBound[g];
+        if (block_a[i] != sa[g] || block_b[i] != sb[g]) bnd = mrc_pack_bound(&h->cfg, block_a[i], block_b[i], 2, 1);   // (refused later)
         if (bnd < 0) return MRC_ERR_INVALID;
         total += bnd;
     }
@@ -159,7 +165,6 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
             MRC_HIP(h, B.ms.reserve((size_t)m * S.nBands * sizeof(int32_t)));
             MRC_HIP(h, B.ev.reserve((size_t)m * nEv * sizeof(unsigned)));
             MRC_HIP(h, B.pre.reserve((size_t)m * (nEv + 1) * sizeof(unsigned)));
-            MRC_HIP(h, B.pos.reserve((size_t)m * nEv * sizeof(unsigned short)));
             MRC_HIP(h, B.bitAlloc.reserve((size_t)m * nTot * sizeof(int32_t)));
             MRC_HIP(h, B.scaleFactor.reserve((size_t)m * nTot * sizeof(int32_t)));
             MRC_HIP(h, B.mant.reserve((size_t)m * nstream * S.halfN * sizeof(uint16_t)));
@@ -172,7 +177,7 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
                                        B.lines.as<double>(), B.oscale.as<int32_t>(), B.ms.as<int32_t>(), B.smr.as<double>(),
                                        B.peak.as<double>(), st, false));
             MRC_HIP(h, launch_chain_prep(S, joint, m, B.smr.as<double>(), joint ? B.ms.as<int32_t>() : nullptr,
-                                         B.ev.as<unsigned>(), B.pre.as<unsigned>(), B.pos.as<unsigned short>(),
+                                         B.ev.as<unsigned>(), B.pre.as<unsigned>(),
                                          h->chainForceFallback ? 1 : 0, st));
         }
         ChainGroupDev& D = desc[g];
@@ -184,7 +189,7 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
         D.bandOfLine = S.bandOfLine; D.bandN = S.bandN;
         D.lines = B.lines.as<double>(); D.peak = B.peak.as<double>(); D.oscale = B.oscale.as<int32_t>();
         D.ms = B.ms.as<int32_t>(); D.ev = B.ev.as<unsigned>();
-        D.pre = B.pre.as<unsigned>(); D.pos = B.pos.as<unsigned short>();
+        D.pre = B.pre.as<unsigned>();
         D.bitAlloc = B.bitAlloc.as<int32_t>(); D.scaleFactor = B.scaleFactor.as<int32_t>();
         D.mant = B.mant.as<unsigned short>(); D.table = B.table.as<int32_t>();
     }
@@ -356,9 +361,24 @@ int mrc_encode_chained_stream_pac(mrc_handle* h, int64_t n_streams, const void* 
                                         block_offset, block_a, block_b, reservoir_in, use_huffman, with_flush, num_samples,
                                         C.out.as<uint8_t>(), bound, stream_byte_offset, item_byte_offset, reservoir_out,
                                         reservoir_trace, total_bytes, h->stream);
+    C.lastTotal = -1;
     if (rc != MRC_OK) return rc;
-    if (*total_bytes > out_cap) return fail(h, MRC_ERR_NOMEM, "mrc_encode_chained_stream_pac: out_cap too small (see total_bytes)");
+    C.lastTotal = *total_bytes;                          // (complete in C.out, whatever the caller's buffer holds)
+    if (*total_bytes > out_cap)
+        return fail(h, MRC_ERR_NOMEM, "mrc_encode_chained_stream_pac: out_cap too small (see total_bytes; mrc_chain_fetch_output)");
     if (*total_bytes) MRC_HIP(h, hipMemcpyAsync(out, C.out.p, (size_t)*total_bytes, hipMemcpyDeviceToHost, h->stream));
+    MRC_HIP(h, hipStreamSynchronize(h->stream));
+    return MRC_OK;
+}
+
+int mrc_chain_fetch_output(mrc_handle* h, uint8_t* out, int64_t out_cap, int64_t* total_bytes) {
+    if (!h || !out || !total_bytes) return fail(h, MRC_ERR_INVALID, "mrc_chain_fetch_output: bad argument");
+    ChainBufs& C = h->chain;
+    if (C.lastTotal < 0) return fail(h, MRC_ERR_INVALID, "mrc_chain_fetch_output: no output of a chained call is held");
+    *total_bytes = C.lastTotal;
+    if (C.lastTotal > out_cap) return fail(h, MRC_ERR_NOMEM, "mrc_chain_fetch_output: out_cap too small (see total_bytes)");
+    MRC_HIP(h, hipSetDevice(h->device));
+    if (C.lastTotal) MRC_HIP(h, hipMemcpyAsync(out, C.out.p, (size_t)C.lastTotal, hipMemcpyDeviceToHost, h->stream));
     MRC_HIP(h, hipStreamSynchronize(h->stream));
     return MRC_OK;
 }

@@ -59,10 +59,10 @@ constexpr int kChainGroups = 5;    // chained encode: the four joint block shape
 // the sorted grant events of the bit allocation, and the outputs of the serial scan (phase B)
 struct ChainGroupBufs {
     DevBuf offsets, lines, oscale, smr, peak, ms;                // phase A
-    DevBuf ev, pre, pos;                                         // prepared for phase B
+    DevBuf ev, pre;                                              // prepared for phase B
     DevBuf bitAlloc, scaleFactor, mant, table, chunkMap;         // phase B outputs, packer inputs
     void release() {
-        for (DevBuf* b : {&offsets, &lines, &oscale, &smr, &peak, &ms, &ev, &pre, &pos, &bitAlloc, &scaleFactor, &mant, &table,
+        for (DevBuf* b : {&offsets, &lines, &oscale, &smr, &peak, &ms, &ev, &pre, &bitAlloc, &scaleFactor, &mant, &table,
                           &chunkMap})
             b->release();
     }
@@ -72,6 +72,7 @@ struct ChainBufs {
     DevBuf pcmL, pcmR, flushPcm, items, itemStart, reservoir, groupDesc, packWs, out, hdr, chunkStream, resTrace, firstChunk,
         streamPos;
     hipEvent_t evT[4] = {};          // phase timing: start | phase A done | phase B done | packed
+    int64_t lastTotal = -1;          // bytes the last mrc_encode_chained_stream_pac left in `out` (-1: none) -- mrc_chain_fetch_output
     void release() {
         for (auto& x : g) x.release();
         for (DevBuf* b : {&pcmL, &pcmR, &flushPcm, &items, &itemStart, &reservoir, &groupDesc, &packWs, &out, &hdr,

@@ -157,7 +157,6 @@ struct ChainGroupDev {               // what chain_phase_b_kernel knows about on
     const int* ms;                   // [n][nb] M/S switch (joint groups)
     const unsigned* ev;              // [n][nEv] grant events in np.argmax's order: band | bitsAfter << 6 | nLines << 11
     const unsigned* pre;             // [n][nEv + 1] bits spent before each event if all before it are granted
-    const unsigned short* pos;       // [n][K][nTot] where each band's k-th grant sits in ev
     int* bitAlloc;                   // [n][nstream][nb]
     int* scaleFactor;                // [n][nstream][nb]
     unsigned short* mant;            // [n][nstream][M]
@@ -165,7 +164,7 @@ struct ChainGroupDev {               // what chain_phase_b_kernel knows about on
 };
 size_t chain_events_per_block(const DevShape& S, int joint);
 hipError_t launch_chain_prep(const DevShape& S, int joint, int64_t nBlocks, const double* smr, const int* msSwitch,
-                             unsigned* ev, unsigned* pre, unsigned short* pos, int forceFallback, hipStream_t st);
+                             unsigned* ev, unsigned* pre, int forceFallback, hipStream_t st);
 hipError_t launch_chain_phase_b(int64_t nStreams, const ChainGroupDev* groups, const int* items, const long long* itemStart,
                                 int* reservoir, int* resTrace, int useHuffman, int threads /* 0: chosen by stream count */,
                                 hipStream_t st);

@@ -95,12 +95,11 @@ __device__ __forceinline__ bool event_before(double ka, int ba, double kb, int b
 constexpr int kPrepWaves = 4;
 __global__ __launch_bounds__(kWave * kPrepWaves) void chain_prep_kernel(
     DevShape S, int joint, int64_t nBlocks, const double* __restrict__ smr, const int* __restrict__ msSwitch,
-    unsigned* __restrict__ evOut, unsigned* __restrict__ preOut, unsigned short* __restrict__ posOut,
+    unsigned* __restrict__ evOut, unsigned* __restrict__ preOut,
     int forceFallback /* tests: scramble the candidate order first */) {
     __shared__ unsigned sEvAll[kPrepWaves][kMaxEvents];
     __shared__ unsigned sPreAll[kPrepWaves][kMaxEvents + 1];
     __shared__ double sKeyAll[kPrepWaves][kMaxEvents];
-    __shared__ unsigned short sPosAll[kPrepWaves][kMaxEvents];
     __shared__ double sPhiAll[kPrepWaves][kWave], sSmrAll[kPrepWaves][kWave];
     __shared__ int sQAll[kPrepWaves][kWave], sSlotAll[kPrepWaves][kWave];
     const int lane = threadIdx.x & (kWave - 1);
@@ -110,7 +109,6 @@ __global__ __launch_bounds__(kWave * kPrepWaves) void chain_prep_kernel(
     unsigned* sEv = sEvAll[wave];
     unsigned* sPre = sPreAll[wave];
     double* sKey = sKeyAll[wave];
-    unsigned short* sPos = sPosAll[wave];
     double* sPhi = sPhiAll[wave];
     double* sSmr = sSmrAll[wave];
     int* sQ = sQAll[wave];
@@ -176,7 +174,6 @@ __global__ __launch_bounds__(kWave * kPrepWaves) void chain_prep_kernel(
             sEv[p] = (unsigned)band | ((unsigned)(k + 2) << 6) | ((unsigned)nB << 11);
             sPre[p] = (unsigned)(costBase + incl - cost);
             sKey[p] = cur;
-            sPos[k * nTot + band] = (unsigned short)p;
             cur -= (k == 0) ? 12.0 : 6.0;
             ++k;
             nextLevel = k >= K ? INT_MIN : (k == 1 ? qB - 2 : nextLevel - 1);
@@ -224,9 +221,8 @@ __global__ __launch_bounds__(kWave * kPrepWaves) void chain_prep_kernel(
             unsigned run = 0;
             for (int p = 0; p < nEv; ++p) {
                 const unsigned e = sEv[p];
-                const int bnd = (int)(e & 63u), after = (int)((e >> 6) & 31u), nn = (int)(e >> 11);
+                const int after = (int)((e >> 6) & 31u), nn = (int)(e >> 11);
                 sPre[p] = run;
-                sPos[(after - 2) * nTot + bnd] = (unsigned short)p;
                 run += (unsigned)(after == 2 ? 2 * nn : nn);
             }
             sPre[nEv] = run;
@@ -235,8 +231,7 @@ __global__ __launch_bounds__(kWave * kPrepWaves) void chain_prep_kernel(
     }
     unsigned* ev = evOut + blk * (int64_t)nEv;
     unsigned* pre = preOut + blk * (int64_t)(nEv + 1);
-    unsigned short* pos = posOut + blk * (int64_t)nEv;
-    for (int p = lane; p < nEv; p += kWave) { ev[p] = sEv[p]; pos[p] = sPos[p]; }
+    for (int p = lane; p < nEv; p += kWave) ev[p] = sEv[p];
     for (int p = lane; p <= nEv; p += kWave) pre[p] = sPre[p];
 }
 
@@ -266,7 +261,6 @@ template <int NT> struct ChainDims {
 // codecThem.py:524-551).
 template <int NT> struct ItemRegs {
     unsigned ev[ChainDims<NT>::kEvPerThread], pre[ChainDims<NT>::kEvPerThread];
-    unsigned short pos[ChainDims<NT>::kEvPerThread];
     double peak;
     double x[ChainDims<NT>::kUnitsPerThread][4];
     unsigned sigs[ChainDims<NT>::kUnitsPerThread];      // signal of each of the unit's four lines, 8 bits each
@@ -301,7 +295,6 @@ struct LoadView {                                       // load side (next items
     const MRC_GLOBAL int* ms;
     const MRC_GLOBAL unsigned* ev;
     const MRC_GLOBAL unsigned* pre;
-    const MRC_GLOBAL unsigned short* pos;
 };
 #define MRC_PIN(x) asm volatile("" : "+s"(x))
 __device__ __forceinline__ GroupView group_view(const ChainGroupDev* __restrict__ groups, int g) {
@@ -326,10 +319,9 @@ __device__ __forceinline__ LoadView load_view(const ChainGroupDev* __restrict__ 
     V.lines = (const MRC_GLOBAL double*)D.lines; V.peak = (const MRC_GLOBAL double*)D.peak;
     V.oscale = (const MRC_GLOBAL int*)D.oscale; V.ms = (const MRC_GLOBAL int*)D.ms;
     V.ev = (const MRC_GLOBAL unsigned*)D.ev; V.pre = (const MRC_GLOBAL unsigned*)D.pre;
-    V.pos = (const MRC_GLOBAL unsigned short*)D.pos;
     MRC_PIN(V.joint); MRC_PIN(V.nb); MRC_PIN(V.nTot); MRC_PIN(V.M); MRC_PIN(V.nEv); MRC_PIN(V.nstream); MRC_PIN(V.nsig);
     MRC_PIN(V.bandOfLine); MRC_PIN(V.bandN); MRC_PIN(V.lines); MRC_PIN(V.peak); MRC_PIN(V.oscale); MRC_PIN(V.ms);
-    MRC_PIN(V.ev); MRC_PIN(V.pre); MRC_PIN(V.pos);
+    MRC_PIN(V.ev); MRC_PIN(V.pre);
     return V;
 }
 // stage 2: the M/S switch of the thread's band and an overall scale, RAW -- what they mean (signal_of) is worked out when
@@ -365,12 +357,10 @@ __device__ __forceinline__ void item_load(const LoadView& G, int64_t idx, int ti
     const int nEv = G.nEv, nTot = G.nTot, M = G.M, nb = G.nb;
     const MRC_GLOBAL unsigned* ev = G.ev + idx * (int64_t)nEv;
     const MRC_GLOBAL unsigned* pre = G.pre + idx * (int64_t)(nEv + 1);
-    const MRC_GLOBAL unsigned short* pos = G.pos + idx * (int64_t)nEv;
 #pragma unroll
     for (int j = 0; j < kEvPerThread; ++j) {
         const int p = tid + NT * j;
         R.ev[j] = p < nEv ? ev[p] : 0u;
-        R.pos[j] = p < nEv ? pos[p] : (unsigned short)0;
         R.pre[j] = p <= nEv ? pre[p] : 0u;
     }
     R.peak = 0.0;
@@ -432,7 +422,6 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
     __shared__ int sBits[kWave];                         // bits granted per (stream, band) while the tail is walked
     __shared__ unsigned sEv[kMaxEvents + kChainThreads];
     __shared__ unsigned sPre[kMaxEvents + kChainThreads];
-    __shared__ unsigned short sPos[kMaxEvents + kChainThreads];
     __shared__ double sPeak[kWave];                      // raw max |X| of the (stream, band)'s signal
     __shared__ int sSig[2][kWave];                       // signal of (stream, band) i: this item's / the next item's (by parity)
     __shared__ int sOsc[2][4];                           // overall scale of signal q, likewise
@@ -523,7 +512,7 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
 #pragma unroll
         for (int j = 0; j < kEvPerThread; ++j) {
             const int p = tid + kChainThreads * j;
-            sEv[p] = R.ev[j]; sPre[p] = R.pre[j]; sPos[p] = R.pos[j];
+            sEv[p] = R.ev[j]; sPre[p] = R.pre[j];
         }
         if (tid < kWave) { sPeak[tid] = R.peak; sSig[par ^ 1][tid] = signal_of(Ln, tid, W.sig); }
         if (tid < 4) sOsc[par ^ 1][tid] = W.osc;
@@ -791,10 +780,10 @@ extern "C" int mrc_debug_chain_profile(unsigned long long* out /*[16]*/, int res
 size_t chain_events_per_block(const DevShape& S, int joint) { return (size_t)(joint ? 2 : 1) * S.nBands * (S.maxMantBits - 1); }
 
 hipError_t launch_chain_prep(const DevShape& S, int joint, int64_t nBlocks, const double* smr, const int* msSwitch,
-                             unsigned* ev, unsigned* pre, unsigned short* pos, int forceFallback, hipStream_t st) {
+                             unsigned* ev, unsigned* pre, int forceFallback, hipStream_t st) {
     if (nBlocks <= 0) return hipSuccess;
     hipLaunchKernelGGL(chain_prep_kernel, dim3((unsigned)((nBlocks + kPrepWaves - 1) / kPrepWaves)), dim3(kWave * kPrepWaves),
-                       0, st, S, joint, nBlocks, smr, msSwitch, ev, pre, pos, forceFallback);
+                       0, st, S, joint, nBlocks, smr, msSwitch, ev, pre, forceFallback);
     return hipGetLastError();
 }
 

@@ -102,6 +102,85 @@ def test_many_streams_with_different_schedules(h):
         assert got[s] == opac.encode_stereo_stream(streams[s], shapes[s], huffman=True), s
 
 
+_LONG_SWITCHED = {}
+
+
+def _long_switched():
+    """a block-switched stereo stream of 600 hops (all four block shapes, > 256 items: the scan's item ring refills while the
+    shapes change) and its bytes from the block-at-a-time loop; built once for the parametrised test below"""
+    if not _LONG_SWITCHED:
+        stream, shapes = _switching_stream(hops=600, seed=9)
+        _LONG_SWITCHED.update(stream=stream, shapes=shapes)
+    return _LONG_SWITCHED
+
+
+@pytest.mark.parametrize("threads", [256, 512, 1024])
+def test_scan_workgroup_sizes_give_the_per_block_bytes(h, threads):
+    # chain_phase_b_kernel exists for 256 / 512 / 1024 threads per stream (two / one / one units of four lines per thread,
+    # different event staging and Huffman accumulators); the library picks 512 for <= 512 streams and 256 above, so the
+    # small-batch tests never run the 256-thread form.  Every form, forced through MRC_OPT_CHAIN_THREADS, on a long
+    # block-switched stream: the bytes and the reservoir after every block equal the block-at-a-time loop's / the oracle's.
+    from mrcaudiocodec_amd import pacfile as ppac
+    from oracle import pacfile as opac
+    d = _long_switched()
+    stream, shapes = d["stream"], d["shapes"]
+    assert len(shapes) > 700 and len({(a, b) for (_, a, b) in shapes}) == 4
+    if "want" not in d:
+        d["want"] = ppac.encode_stereo_stream_per_block(h, stream, shapes, use_huffman=True)
+        n40 = 40
+        d["prefix"] = opac.encode_stereo_stream(stream[:, :shapes[n40 - 1][0] + shapes[n40 - 1][1] + shapes[n40 - 1][2]],
+                                                shapes[:n40], huffman=True)
+    h.set_option(4, threads)
+    try:
+        got = ppac.encode_stereo_stream(h, stream, shapes, use_huffman=True)
+        r = h.encode_chained_pac(stream[0][None], stream[1][None], [shapes], want_trace=True)
+        short = ppac.encode_stereo_stream(h, stream, shapes[:40], use_huffman=True)
+    finally:
+        h.set_option(4, 0)
+    assert got == d["want"]
+    assert short == d["prefix"]                                       # ... and the oracle on a prefix
+    trace = np.asarray(r["reservoir_trace"])
+    if "trace" not in d:
+        d["trace"] = trace
+    assert np.array_equal(trace, d["trace"])                          # the same reservoir after every block in every form
+
+
+def test_many_streams_take_the_256_thread_scan(h):
+    # > 512 streams: the library's own choice is the 256-thread scan.  600 streams made of 6 different ones (different
+    # block-shape schedules and lengths), each file byte for byte what the stream gives when encoded alone.
+    from mrcaudiocodec_amd import pacfile as ppac, synth
+    hops = 9
+    x, sh_sw = synth.c4_transients(hops)
+    tone = synth.c1_sine(hops)
+    g = synth.c2_noise(hops, seed=3, sigma=0.05)
+    sh_long = [(i * 1024, 1024, 1024) for i in range(hops - 1)]
+    n = len(tone)
+    base = [np.stack([x + 0.3 * tone, 0.7 * x + 0.3 * tone + 0.05 * g])[:, :n], np.stack([tone, 0.9 * tone]),
+            np.stack([0.5 * tone + g, 0.5 * tone - g]), np.zeros((2, n)), np.stack([g, 0.2 * tone]),
+            np.stack([0.4 * tone, g])]
+    base_shapes = [sh_sw, sh_long, sh_long[:6], sh_long[:4], sh_sw, sh_long[:1]]
+    alone = [ppac.encode_stereo_stream(h, base[i], base_shapes[i]) for i in range(6)]
+    pick = (np.arange(600) * 7) % 6
+    got = ppac.encode_stereo_streams(h, np.stack([base[i] for i in pick]), [base_shapes[i] for i in pick])
+    assert h.get_option(4) == 0
+    for s, i in enumerate(pick):
+        assert got[s] == alone[i], (s, i)
+
+
+def test_output_beyond_the_first_buffer_is_fetched(h):
+    # the binding's first buffer holds ~1 KB per block; at 12 bits per sample a block packs to more: the call reports the size
+    # and the bytes -- complete in the handle's device buffer -- are fetched (mrc_chain_fetch_output), not encoded again
+    from mrcaudiocodec_amd import Handle, pacfile as ppac
+    hd = Handle(target_bits_per_sample=12.0)
+    try:
+        stream, shapes = _switching_stream(hops=12, seed=3)
+        got = ppac.encode_stereo_stream(hd, stream, shapes)
+        assert len(got) > len(shapes) * 1024 + 2 * 4096
+        assert got == ppac.encode_stereo_stream_per_block(hd, stream, shapes)
+    finally:
+        hd.close()
+
+
 def test_pcm16_input_equals_float_input(h):
     from mrcaudiocodec_amd import synth
     rng = np.random.default_rng(11)

@@ -143,6 +143,8 @@ def test_round_trip_on_device_at_scale(h):
     stream = np.stack([tone, 0.9 * tone])
     shapes = [(i * 1024, 1024, 1024) for i in range(hops - 1)]
     pac = ppac.encode_stereo_stream(h, stream, shapes, use_huffman=True)
+    # (the chained call walks > 256 items of one stream here: its item ring refills; byte for byte the block-at-a-time loop)
+    assert pac == ppac.encode_stereo_stream_per_block(h, stream, shapes, use_huffman=True)
     nch, x = ppac.decode_pac(h, pac)
     x = x.cpu().numpy()
     ref, dec = stream[:, 2048:(hops - 1) * 1024], x[:, 2048:(hops - 1) * 1024]

@@ -1,7 +1,7 @@
 """
 GPU tests at the FULL batch sizes of BASELINE.json's configurations (2^20 mono frames per GPU; configs[4]'s
-10^7 stereo frames over 8 GPUs = 1.25 * 10^6 per GPU, here 2^19 joint frames), where the oracle would take days: the
-size-independent properties of the path instead --
+10^7 stereo frames over 8 GPUs = 1 250 000 joint frames per GPU, ~54 GB of HBM: 5.12e9 MDCT lines in one buffer, beyond any
+32-bit index), where the oracle would take days: the size-independent properties of the path instead --
 
   * sharding / linearity: the batch encoded in one launch set == the same stream cut into contiguous shards (each with its
     one-hop halo, as a rank would hold it) and encoded shard by shard;
@@ -122,12 +122,13 @@ def test_full_size_mono_batch_properties():
 
 
 def test_full_size_joint_batch_properties():
-    """configs[2] / the per-GPU share of configs[4]: 2^19 long joint stereo frames (C3 content), 8 shards"""
+    """the per-GPU share of configs[4] at its real size: 1 250 000 long joint stereo frames (C3 content; bench.py's
+    --c4-frames default), cut into 8 shards -- what each rank of the 8-GPU job holds, here all on one GPU"""
     import refgold as G
     from oracle import fast
     torch, bench, pacfile, enc, cfg = _env()
     dev = torch.device("cuda", 0)
-    F = 1 << 19
+    F = 10 ** 7 // 8
     chans = _whole_stream(torch, bench, dev, "c3", F)
 
     def oracle_check(frames, host, sample):
