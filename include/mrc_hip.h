@@ -389,6 +389,31 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
                                uint8_t* out, int64_t out_cap, int64_t* stream_byte_offset, int64_t* item_byte_offset,
                                int32_t* reservoir_out, int32_t* reservoir_trace, int64_t* total_bytes, void* stream);
 int mrc_get_chain_ms(mrc_handle* h, double* ms /*[4]*/);
+
+/* ---- sensitivity certificate (round 4) ----
+ * Bit-identity of the integers with the reference is an empirical, counted result: each of them is a floor / compare of
+ * float64 values whose last bits differ between implementations (FFT factorisation, log10 / atan / 2^x), and it can only come
+ * out differently where the deciding value lies within that difference of its edge.  With MRC_OPT_SENSITIVITY set, the
+ * encode calls of a handle count those places; counts [MRC_SENS_COUNT] accumulate until reset:
+ *   MRC_SENS_QUANT     mantissa codes within 4e-13 (of the block's scaled peak) of their truncation edge, and scale factors
+ *                      decided by a band peak that close to a power-of-two code (quantize.py:12-38,114-146,294-322)
+ *   MRC_SENS_BITALLOC  pairs of bands whose SMRs are a multiple of 6 dB apart to within 1e-9 dB: their running values tie
+ *                      at some step of the greedy loop (bitalloc.py:132-151, np.argmax)
+ *   MRC_SENS_MS        bands whose M/S test is within 1e-12 (relative) of its 0.8 threshold (ms_stereo.py:5-27)
+ *   MRC_SENS_PEAK      spectral bins within 1e-11 (relative) of a neighbour they have to beat strictly (psychoac.py:162)
+ *   MRC_SENS_NODES     64-line chunks the slope-node evaluation of the masking sum sent back to the sorted sweep (its error
+ *                      bound exceeded 1e-13 of a line's masked intensity) -- informational: the result is then the sweep's
+ *   MRC_SENS_FRAMES    blocks examined
+ * A call whose first four counts are zero took no decision near an edge.  Not counted: the overall scale (a 20-bit code of
+ * the block peak), the transient detector's threshold tests.  Synchronises the handle's stream. */
+#define MRC_SENS_QUANT 0
+#define MRC_SENS_BITALLOC 1
+#define MRC_SENS_MS 2
+#define MRC_SENS_PEAK 3
+#define MRC_SENS_NODES 4
+#define MRC_SENS_FRAMES 5
+#define MRC_SENS_COUNT 8
+int mrc_get_sensitivity(mrc_handle* h, int64_t* counts /*[MRC_SENS_COUNT]*/, int reset);
 /* mrc_chain_fetch_output: the bytes of the LAST mrc_encode_chained_stream[_pcm16]_pac call on this handle, which stay in the
  * handle's device buffer until the next chained call: after MRC_ERR_NOMEM ("out_cap too small") a caller allocates
  * total_bytes and fetches them -- no second encode.  The offsets / reservoirs of that call were already returned by it. */
@@ -448,6 +473,10 @@ int mrc_set_timing(mrc_handle* h, int enabled);
 /* MRC_OPT_CHAIN_THREADS = 0 | 256 | 512 | 1024: threads of the workgroup that walks one stream in the chained encode's
  * serial scan (default 0: 512 for up to 512 streams -- the latency of the one stream counts -- else 256: eight streams per CU). */
 #define MRC_OPT_CHAIN_THREADS 4
+/* MRC_OPT_SENSITIVITY = 1: every encode call on the handle also counts the integer decisions it took within a guard band of
+ * floating-point rounding (see mrc_get_sensitivity); costs a pass over the intermediate results (~10 % of an encode).
+ * = 2 (tests): the same with every guard band a million times wider, so that an ordinary corpus produces counts. */
+#define MRC_OPT_SENSITIVITY 5
 int mrc_set_option(mrc_handle* h, int option, int value);
 int mrc_get_option(mrc_handle* h, int option, int32_t* value);
 int mrc_get_stage_ms(mrc_handle* h, double* ms /*[3]*/);

@@ -145,6 +145,7 @@ def _load():
         "mrc_pack_joint_blocks": (C.c_int, [C.POINTER(MrcConfig), C.c_int64, C.c_int, C.c_int, C.c_int, _i32p, _i32p,
                                             _i32p, _i32p, _i32p, _u8p, C.c_int64, _i64p, _i32p, _i32p]),
         "mrc_chain_fetch_output": (C.c_int, [H, C.c_void_p, C.c_int64, _i64p]),
+        "mrc_get_sensitivity": (C.c_int, [H, _i64p, C.c_int]),
         "mrc_set_timing": (C.c_int, [H, C.c_int]),
         "mrc_set_option": (C.c_int, [H, C.c_int, C.c_int]),
         "mrc_get_option": (C.c_int, [H, C.c_int, _i32p]),
@@ -702,6 +703,16 @@ class Handle:
         v = C.c_int32()
         self._check(lib.mrc_get_option(self._h, int(option), C.byref(v)))
         return v.value
+
+    SENS_NAMES = ("quantiser_edges", "bitalloc_near_ties", "ms_switch_near_threshold", "peak_near_ties",
+                  "node_chunks_sent_back", "blocks_examined")
+
+    def sensitivity(self, reset=True):
+        """mrc_get_sensitivity: with set_option(5, 1) (MRC_OPT_SENSITIVITY) the encode calls count the integer decisions
+        taken within a guard band of floating-point rounding -> dict name -> count since the last reset."""
+        v = np.zeros(8, np.int64)
+        self._check(lib.mrc_get_sensitivity(self._h, _p(v, _i64p), 1 if reset else 0))
+        return {n: int(v[i]) for i, n in enumerate(self.SENS_NAMES)}
 
     def set_timing(self, on):
         self._check(lib.mrc_set_timing(self._h, int(bool(on))))

@@ -61,8 +61,12 @@ def read_wav(path, hop=1024):
     return rate, n_ch, num_samples, np.where(mag >= 32768, 0.0, np.sign(c) * 2.0 * mag / 65535)
 
 
-def encode_wav(in_path, out_path=None, use_huffman=True, device_id=0, handle=None, exact_spread=False):
-    """exact_spread: evaluate the masker spreading operation by operation like psychoac.py:68-78 (MRC_OPT_EXACT_SPREAD,
+def encode_wav(in_path, out_path=None, use_huffman=True, device_id=0, handle=None, exact_spread=False, certify=None):
+    """certify: a dict to fill with the sensitivity certificate of the encode (mrc_get_sensitivity: how many integer decisions
+    were taken within a guard band of floating-point rounding); if any was, the file is encoded once more with the masker
+    spreading evaluated operation by operation (MRC_OPT_EXACT_SPREAD) and certify["bytes_equal_exact_spread"] says whether
+    the two encodes gave the same bytes.
+    exact_spread: evaluate the masker spreading operation by operation like psychoac.py:68-78 (MRC_OPT_EXACT_SPREAD,
     ~30x slower kernel).  Both modes give the reference driver's bytes on every fixture and sweep; neither is
     bit-identical by construction (README.md, "Parity").
     The file's int16 codes go to the device as they are: the transient detector (mrc_transient_peaks_ex) and the whole
@@ -72,8 +76,12 @@ def encode_wav(in_path, out_path=None, use_huffman=True, device_id=0, handle=Non
         raise ValueError("stereo input only (the reference's JointEncode indexes data[0], data[1])")
     h = handle if handle is not None else Handle(sample_rate=rate, device_id=device_id)
     was_exact = h.get_option(1)
+    was_sens = h.get_option(5)
     if exact_spread:
         h.set_option(1, 1)
+    if certify is not None:
+        h.set_option(5, 1)
+        h.sensitivity()
     try:
         L = h.cfg.n_mdct_lines
         codes = np.concatenate([np.zeros((2, L), np.int16), pcm], axis=1)      # the zero prior hop (pacfileThem.py:615-618)
@@ -85,9 +93,20 @@ def encode_wav(in_path, out_path=None, use_huffman=True, device_id=0, handle=Non
         r = h.encode_chained_pac(codes[0][None], codes[1][None], [shapes], use_huffman=use_huffman, with_flush=True,
                                  num_samples=[num_samples])
         data = r["bytes"].tobytes()
+        if certify is not None:
+            certify.update(h.sensitivity())
+            near = sum(certify[k] for k in ("quantiser_edges", "bitalloc_near_ties", "ms_switch_near_threshold", "peak_near_ties"))
+            certify["decisions_near_an_edge"] = near
+            if near and not exact_spread:
+                h.set_option(5, 0)
+                h.set_option(1, 1)
+                again = h.encode_chained_pac(codes[0][None], codes[1][None], [shapes], use_huffman=use_huffman, with_flush=True,
+                                             num_samples=[num_samples])
+                certify["bytes_equal_exact_spread"] = again["bytes"].tobytes() == data
     finally:
-        if exact_spread and handle is not None:
-            h.set_option(1, was_exact)           # (a caller's handle gets back the setting it came with)
+        if handle is not None:
+            h.set_option(1, was_exact)           # (a caller's handle gets back the settings it came with)
+            h.set_option(5, was_sens)
         if handle is None:
             h.close()
     if out_path:
@@ -130,14 +149,26 @@ def main(argv=None):
     ap.add_argument("--no-huffman", action="store_true")
     ap.add_argument("--exact-spread", action="store_true",
                     help="masker spreading operation by operation as in psychoac.py:68-78 (slower kernel)")
+    ap.add_argument("--certify", action="store_true",
+                    help="report how many integer decisions of the encode lay within a guard band of floating-point rounding "
+                         "(quantiser edges, bit-allocation ties, M/S threshold, peak test); if any did, encode again with "
+                         "--exact-spread and say whether the bytes are the same")
     ap.add_argument("--device", type=int, default=0)
     a = ap.parse_args(argv)
     if a.decode:
         pcm = decode_pac_file(a.src, a.dst, a.device)
         print("%s: %d channels x %d samples" % (a.dst, pcm.shape[0], pcm.shape[1]))
         return
-    data = encode_wav(a.src, a.dst, not a.no_huffman, a.device, exact_spread=a.exact_spread)
+    cert = {} if a.certify else None
+    data = encode_wav(a.src, a.dst, not a.no_huffman, a.device, exact_spread=a.exact_spread, certify=cert)
     print("%s: %d bytes" % (a.dst, len(data)))
+    if cert is not None:
+        print("certificate: %d blocks examined; decisions within a guard band of rounding: %d (quantiser edges %d, "
+              "bit-allocation ties %d, M/S threshold %d, peak test %d); chunks the slope-node evaluation sent back: %d"
+              % (cert["blocks_examined"], cert["decisions_near_an_edge"], cert["quantiser_edges"], cert["bitalloc_near_ties"],
+                 cert["ms_switch_near_threshold"], cert["peak_near_ties"], cert["node_chunks_sent_back"]))
+        if "bytes_equal_exact_spread" in cert:
+            print("  re-encoded with --exact-spread: bytes %s" % ("identical" if cert["bytes_equal_exact_spread"] else "DIFFER"))
 
 
 if __name__ == "__main__":

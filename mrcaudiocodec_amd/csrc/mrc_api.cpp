@@ -109,6 +109,9 @@ void mrc_destroy(mrc_handle* h) {
     for (DevBuf* b : {&h->inL, &h->inR, &h->inAux, &h->inAux2, &h->inAux3,
                       &h->outA, &h->outB, &h->outC, &h->outD, &h->outE, &h->outF, &h->outG})
         b->release();
+    h->sens.release();
+    h->pinIn.release();
+    h->pinOut.release();
     for (auto& ev : h->ev) if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -150,6 +153,21 @@ int mrc_set_option(mrc_handle* h, int option, int value) {
     if (option == MRC_OPT_EXACT_SPREAD) { h->exactSpread = value != 0; return MRC_OK; }
     if (option == MRC_OPT_SMR_ALL_BANDS) { h->smrAllBands = value != 0; return MRC_OK; }
     if (option == MRC_OPT_CHAIN_FORCE_REPAIR) { h->chainForceFallback = value != 0; return MRC_OK; }
+    if (option == MRC_OPT_SENSITIVITY) {
+        if (value < 0 || value > 2) return fail(h, MRC_ERR_INVALID, "mrc_set_option: MRC_OPT_SENSITIVITY takes 0, 1 or 2");
+        if (value) {
+            MRC_HIP(h, hipSetDevice(h->device));
+            MRC_HIP(h, hipStreamSynchronize(h->stream));
+            if (!h->sens.p) {
+                MRC_HIP(h, h->sens.reserve(MRC_SENS_COUNT * sizeof(unsigned long long)));
+                MRC_HIP(h, hipMemset(h->sens.p, 0, MRC_SENS_COUNT * sizeof(unsigned long long)));
+            }
+            const double scale = value == 2 ? 1e6 : 1.0;                 // slot 7: the guard scale the kernels read
+            MRC_HIP(h, hipMemcpy(h->sens.as<unsigned long long>() + 7, &scale, sizeof scale, hipMemcpyHostToDevice));
+        }
+        h->sensOn = value != 0;
+        return MRC_OK;
+    }
     if (option == MRC_OPT_CHAIN_THREADS) {
         if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(h, MRC_ERR_INVALID, "mrc_set_option: MRC_OPT_CHAIN_THREADS takes 0, 256, 512 or 1024");
         h->chainThreads = value;
@@ -165,8 +183,22 @@ int mrc_get_option(mrc_handle* h, int option, int32_t* value) {
         case MRC_OPT_SMR_ALL_BANDS: *value = h->smrAllBands ? 1 : 0; return MRC_OK;
         case MRC_OPT_CHAIN_FORCE_REPAIR: *value = h->chainForceFallback ? 1 : 0; return MRC_OK;
         case MRC_OPT_CHAIN_THREADS: *value = h->chainThreads; return MRC_OK;
+        case MRC_OPT_SENSITIVITY: *value = h->sensOn ? 1 : 0; return MRC_OK;
         default: return fail(h, MRC_ERR_INVALID, "mrc_get_option: unknown option");
     }
+}
+
+int mrc_get_sensitivity(mrc_handle* h, int64_t* counts, int reset) {
+    if (!h || !counts) return MRC_ERR_INVALID;
+    for (int i = 0; i < MRC_SENS_COUNT; ++i) counts[i] = 0;
+    if (!h->sens.p) return MRC_OK;
+    MRC_HIP(h, hipSetDevice(h->device));
+    MRC_HIP(h, hipStreamSynchronize(h->stream));
+    unsigned long long v[MRC_SENS_COUNT];
+    MRC_HIP(h, hipMemcpy(v, h->sens.p, sizeof v, hipMemcpyDeviceToHost));
+    for (int i = 0; i < MRC_SENS_COUNT - 1; ++i) counts[i] = (int64_t)v[i];   // (slot 7 is the guard scale)
+    if (reset) MRC_HIP(h, hipMemset(h->sens.p, 0, (MRC_SENS_COUNT - 1) * sizeof(unsigned long long)));
+    return MRC_OK;
 }
 
 int mrc_get_stage_ms(mrc_handle* h, double* ms) {
@@ -354,7 +386,8 @@ int encode_phase_a(mrc_handle* h, const DevShape& S, int64_t n, const void* chL,
                                     4 * (int64_t)S.halfN, S.halfN, msSwitch, st));
     if (timing) MRC_HIP(h, hipEventRecord(h->ev[2], st));
     MRC_HIP(h, launch_smr(S, n, chL, chR, fmt, stride, offsets, lines, oscale, smr, nullptr, peak,
-                          (joint && !h->smrAllBands) ? msSwitch : nullptr, h->exactSpread, st));
+                          (joint && !h->smrAllBands) ? msSwitch : nullptr, h->exactSpread, st,
+                          h->sensOn ? h->sens.as<unsigned long long>() : nullptr));
     if (timing) MRC_HIP(h, hipEventRecord(h->ev[3], st));
     return MRC_OK;
 }
@@ -385,6 +418,9 @@ int encode_core(mrc_handle* h, const DevShape& S, int64_t n, const void* chL, co
                            timing));
     MRC_HIP(h, launch_alloc_quant(S, n, joint, lines, oscale, smr, resIn, msSwitch, bitAlloc, scaleFactor, mantissa,
                                   mantFmt, resOut, ws.peak.as<double>(), true, true, timing ? &h->ev[3] : nullptr, st));
+    if (h->sensOn)                                       // (after the timed kernels; outside their events)
+        MRC_HIP(h, launch_sensitivity(S, n, joint, lines, oscale, smr, ws.peak.as<double>(), msSwitch, bitAlloc, scaleFactor,
+                                      h->sens.as<unsigned long long>(), nullptr, st));
     if (timing) {
         MRC_HIP(h, hipEventRecord(h->ev[5], st));
         MRC_HIP(h, hipEventSynchronize(h->ev[5]));
@@ -455,6 +491,8 @@ struct Staged {
     }
 };
 
+constexpr int64_t kSmallBatch = 64;               // calls with at most this many blocks go through one page-locked buffer each way
+
 int encode_host(mrc_handle* h, int64_t n, int a, int b, const double* left, const double* right,
                 const int32_t* reservoir_in, int32_t* overall_scale, int32_t* ms_switch, int32_t* scale_factor,
                 int32_t* bit_alloc, int32_t* mantissa, int32_t* reservoir_out, double* mdct_out) {
@@ -468,13 +506,53 @@ int encode_host(mrc_handle* h, int64_t n, int a, int b, const double* left, cons
     MRC_HIP(h, hipSetDevice(h->device));
     Staged s{h, h->stream};
     const size_t inBytes = (size_t)n * S.N * sizeof(double);
-    MRC_TRY(s.up(h->inL, left, inBytes));
-    if (joint) MRC_TRY(s.up(h->inR, right, inBytes));
-    if (reservoir_in) MRC_TRY(s.up(h->inAux, reservoir_in, (size_t)n * sizeof(int32_t)));
     const size_t szScale = (size_t)n * nsig * sizeof(int32_t), szSw = (size_t)n * S.nBands * sizeof(int32_t);
     const size_t szBand = (size_t)n * nstream * S.nBands * sizeof(int32_t);
     const size_t szMant = (size_t)n * nstream * S.halfN * sizeof(int32_t), szRes = (size_t)n * sizeof(int32_t);
     const size_t szLines = (size_t)n * nsig * S.halfN * sizeof(double);
+    if (n <= kSmallBatch) {
+        // The per-block seam (pacfileThem.py:649,820 -> codecThem.py:205-278 hands over ONE block per call): every array in
+        // its own pageable copy cost more than the kernels (ten copies, each a staging round trip of the runtime).  Few
+        // blocks travel as ONE page-locked buffer each way: inputs packed by the host, outputs laid out back to back on the
+        // device -- [lines][scale][switch][sf][ba][mantissa][reservoir], each 16-byte aligned.
+        auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        const size_t oIn[4] = {0, al(inBytes), al(inBytes) + (joint ? al(inBytes) : 0), 0};
+        const size_t inTotal = oIn[2] + al(szRes);
+        MRC_HIP(h, h->pinIn.reserve(inTotal));
+        MRC_HIP(h, h->inL.reserve(inTotal));
+        char* pin = (char*)h->pinIn.p;
+        std::memcpy(pin, left, inBytes);
+        if (joint) std::memcpy(pin + oIn[1], right, inBytes);
+        if (reservoir_in) std::memcpy(pin + oIn[2], reservoir_in, szRes);
+        MRC_HIP(h, hipMemcpyAsync(h->inL.p, pin, reservoir_in ? inTotal : oIn[2], hipMemcpyHostToDevice, h->stream));
+        char* din = (char*)h->inL.p;
+        const size_t oLines = 0, oScale = al(mdct_out ? szLines : 0), oSw = oScale + al(szScale), oSf = oSw + al(joint ? szSw : 0),
+                     oBa = oSf + al(szBand), oMant = oBa + al(szBand), oRes = oMant + al(szMant), outTotal = oRes + al(szRes);
+        MRC_HIP(h, h->outA.reserve(outTotal));
+        if (!mdct_out) MRC_HIP(h, h->outG.reserve(szLines));
+        char* dout = (char*)h->outA.p;
+        MRC_TRY(mrc_dev_encode(h, a, b, n, (const double*)din, joint ? (const double*)(din + oIn[1]) : nullptr, S.N, nullptr,
+                               reservoir_in ? (const int32_t*)(din + oIn[2]) : nullptr, (int32_t*)(dout + oScale),
+                               (int32_t*)(dout + oSw), (int32_t*)(dout + oBa), (int32_t*)(dout + oSf),
+                               (int32_t*)(dout + oMant), (int32_t*)(dout + oRes),
+                               mdct_out ? (double*)(dout + oLines) : h->outG.as<double>(), h->stream));
+        MRC_HIP(h, h->pinOut.reserve(outTotal));
+        const size_t from = mdct_out ? 0 : oScale;               // (the lines only travel when asked for)
+        char* pout = (char*)h->pinOut.p;
+        MRC_HIP(h, hipMemcpyAsync(pout + from, dout + from, outTotal - from, hipMemcpyDeviceToHost, h->stream));
+        MRC_HIP(h, hipStreamSynchronize(h->stream));
+        if (mdct_out) std::memcpy(mdct_out, pout + oLines, szLines);
+        std::memcpy(overall_scale, pout + oScale, szScale);
+        if (joint) std::memcpy(ms_switch, pout + oSw, szSw);
+        std::memcpy(scale_factor, pout + oSf, szBand);
+        std::memcpy(bit_alloc, pout + oBa, szBand);
+        std::memcpy(mantissa, pout + oMant, szMant);
+        std::memcpy(reservoir_out, pout + oRes, szRes);
+        return MRC_OK;
+    }
+    MRC_TRY(s.up(h->inL, left, inBytes));
+    if (joint) MRC_TRY(s.up(h->inR, right, inBytes));
+    if (reservoir_in) MRC_TRY(s.up(h->inAux, reservoir_in, (size_t)n * sizeof(int32_t)));
     MRC_HIP(h, h->outA.reserve(szScale)); MRC_HIP(h, h->outB.reserve(szSw)); MRC_HIP(h, h->outC.reserve(szBand));
     MRC_HIP(h, h->outD.reserve(szBand));  MRC_HIP(h, h->outE.reserve(szMant)); MRC_HIP(h, h->outF.reserve(szRes));
     MRC_HIP(h, h->outG.reserve(szLines));

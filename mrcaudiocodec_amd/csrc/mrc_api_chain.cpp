@@ -266,6 +266,15 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
                                     C.reservoir.as<int>(), reservoir_trace ? C.resTrace.as<int>() : nullptr,
                                     use_huffman ? 1 : 0, h->chainThreads, st));
     MRC_HIP(h, hipEventRecord(C.evT[2], st));
+    if (h->sensOn)                                       // MRC_OPT_SENSITIVITY: the scan's decisions, group by group
+        for (int g = 0; g < nGroups; ++g) {
+            ChainGroupBufs& B = C.g[g];
+            const int joint = g == 4 ? 0 : 1;
+            MRC_HIP(h, launch_sensitivity(hs[g]->dev, count[g], joint, B.lines.as<double>(), B.oscale.as<int32_t>(),
+                                          B.smr.as<double>(), B.peak.as<double>(), joint ? B.ms.as<int32_t>() : nullptr,
+                                          B.bitAlloc.as<int32_t>(), B.scaleFactor.as<int32_t>(),
+                                          h->sens.as<unsigned long long>(), nullptr, st));
+        }
     // ---- pack: plan per shape, ONE prefix sum over the chunks in file order, write per shape
     static const PackTables tables = [] { PackTables t; pack_tables(&t); return t; }();
     MRC_HIP(h, C.packWs.reserve(pack_workspace_bytes(nChunks)));

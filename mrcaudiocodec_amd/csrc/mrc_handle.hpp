@@ -25,6 +25,22 @@ struct DevBuf {
     template <class T> T* as() { return (T*)p; }
 };
 
+// page-locked host staging of the small-batch host entry points (one copy each way instead of one per array)
+struct PinnedBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 // intermediate results of one encode call (lines, SMRs, band peaks); one set per stream that encodes concurrently
 struct Workspace {
     DevBuf lines, smr, peak;
@@ -99,6 +115,7 @@ struct mrc_handle {
                                      //     one of the others and serialise with it: 10 000 instead of 19 000 Msamples/s)
     // staging of the host entry points
     mrc::DevBuf inL, inR, inAux, inAux2, inAux3, outA, outB, outC, outD, outE, outF, outG;
+    mrc::PinnedBuf pinIn, pinOut;    // ... of calls with few blocks (the per-block seam): one H2D, one D2H
     mrc::DevBuf packWs;              // mrc_dev_pack_blocks: chunk sizes / positions / (table ids)
     int64_t packLastChunks = 0, packLastCap = 0;   // ... of the most recent call (mrc_dev_pack_status)
     mrc::ChainBufs chain;            // mrc_encode_chained_*: see mrc_api_chain.cpp
@@ -108,6 +125,8 @@ struct mrc_handle {
     bool smrAllBands = false;        // mrc_set_option(MRC_OPT_SMR_ALL_BANDS)
     int chainThreads = 0;            // mrc_set_option(MRC_OPT_CHAIN_THREADS): workgroup size of the serial scan, 0 = by stream count
     bool chainForceFallback = false; // mrc_set_option(MRC_OPT_CHAIN_FORCE_REPAIR): tests of chain_prep_kernel's repair pass
+    bool sensOn = false;             // mrc_set_option(MRC_OPT_SENSITIVITY): count decisions near a rounding edge ...
+    mrc::DevBuf sens;                // ... here: MRC_SENS_COUNT counters (uint64), mrc_get_sensitivity
     hipEvent_t ev[mrc::kKernelEvents] = {};
     double stageMs[3] = {0, 0, 0};
     double kernelMs[5] = {0, 0, 0, 0, 0};

@@ -85,7 +85,12 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
                       int64_t stride, const int64_t* offsets, const double* lines, const int* oscale,
                       double* smr, double* thresh, double* bandPeak /* [frames*signals][nBands] or null */,
                       const int* msSwitch /* joint: [frames][nBands] -> only the SMRs the encoder uses are computed; null: all */,
-                      bool exactSpread, hipStream_t st);
+                      bool exactSpread, hipStream_t st,
+                      unsigned long long* sens = nullptr /* MRC_OPT_SENSITIVITY: counters [MRC_SENS_COUNT] on the device */);
+// mrc_kernels_sens.hip: decisions within a guard band of rounding (quantiser edges, allocation ties, M/S threshold)
+hipError_t launch_sensitivity(const DevShape& S, int64_t nFrames, int joint, const double* lines, const int* oscale,
+                              const double* smr, const double* bandPeak, const int* msSwitch, const int* bitAlloc,
+                              const int* scaleFactor, unsigned long long* sens, unsigned char* frameFlags, hipStream_t st);
 hipError_t launch_alloc_quant(const DevShape& S, int64_t nFrames, int joint, const double* lines,
                               const int* oscale, const double* smr, const int* resIn, int* msSwitch,
                               int* bitAlloc, int* scaleFactor, void* mantissa, int mantFmt /* MRC_MANTISSA_* */,

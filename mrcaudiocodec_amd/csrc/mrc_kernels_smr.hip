@@ -691,7 +691,8 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                                          const int64_t* __restrict__ offsetsArg, const double* __restrict__ lines,
                                          const int* __restrict__ oscale, double* __restrict__ smr,
                                          double* __restrict__ threshArg, double* __restrict__ bandPeakArg,
-                                         const int* __restrict__ msSwitch, SmrLds layArg) {
+                                         const int* __restrict__ msSwitch, SmrLds layArg,
+                                         unsigned long long* __restrict__ sens) {
     extern __shared__ double smem[];
     const SmrLds lay = DIM ? smr_layout(DIM, DIM, DIM - 100, nullptr) : layArg;
     __shared__ int waveCnt[NT / kWave];
@@ -877,6 +878,18 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     const int p1 = min(p0 + per, last - 1);
     int mine = 0;
     for (int p = p0; p < p1; ++p) mine += (xi[p] > xi[p - 1] && xi[p] > xi[p + 1]) ? 1 : 0;
+    if (sens) {
+        // MRC_OPT_SENSITIVITY: strict comparisons of psychoac.py:162 that a relative change of kPeakGuard in a bin would turn
+        // round (a bin within the guard of a neighbour it has to beat, while it does not clearly lose against the other one)
+        const double kPeakGuard = 1e-11 * __longlong_as_double((long long)sens[7]);    // (sens[7]: guard scale, 1 or 1e6)
+        int near = 0;
+        for (int p = p0; p < p1; ++p) {
+            const double c = xi[p], l = xi[p - 1], r = xi[p + 1];
+            const bool nl = fabs(c - l) <= kPeakGuard * c, nr = fabs(c - r) <= kPeakGuard * c;
+            near += ((nl && (c > r || nr)) || (nr && (c > l || nl))) ? 1 : 0;
+        }
+        if (near) atomicAdd(&sens[3], (unsigned long long)near);
+    }
     const int incl = wave_incl_scan(mine, lane);
     if (lane == kWave - 1) waveCnt[wave] = incl;
     __syncthreads();
@@ -1293,6 +1306,7 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 if (!MRC_PROFILE_NODESKIP && __any(!(errBound <= kNodeTol * t))) {
                     // a line of this chunk lives on what the interpolation does worst: the chunk goes back to the sorted sweep
                     MRC_NODE_COUNT(3);
+                    if (sens && lane == 0) atomicAdd(&sens[4], 1ull);
                     const double tot = cur.quiet + upper_cold<TAB>(mt, e2tab, S.zb, M, c, lane, nUp, cnt, cur.z, slMid, spreadHalf);
                     t = tail_sum(tot, cnt, __builtin_amdgcn_readlane(nUp, kWave - 1), cur.lowE);
                 } else {
@@ -1380,9 +1394,10 @@ __global__ __launch_bounds__(NT) MRC_SMR_OCC void smr_kernel(DevShape S, int nsi
                                                        const double* __restrict__ lines,
                                                        const int* __restrict__ oscale, double* __restrict__ smr,
                                                        double* __restrict__ threshArg, double* __restrict__ bandPeakArg,
-                                                       const int* __restrict__ msSwitch, SmrLds layArg) {
+                                                       const int* __restrict__ msSwitch, SmrLds layArg,
+                                                       unsigned long long* __restrict__ sens) {
     smr_body<EXACT, SampleT, NT, DIM, MODE>(S, nsigArg, chL, chR, stride, offsetsArg, lines, oscale, smr, threshArg,
-                                                   bandPeakArg, msSwitch, layArg);
+                                            bandPeakArg, msSwitch, layArg, sens);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1592,7 +1607,7 @@ extern "C" int mrc_debug_phase_cycles(unsigned long long* out16, int reset) {
 
 hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const void* chR, int fmt, int64_t stride,
                       const int64_t* offsets, const double* lines, const int* oscale, double* smr, double* thresh,
-                      double* bandPeak, const int* msSwitch, bool exactSpread, hipStream_t st) {
+                      double* bandPeak, const int* msSwitch, bool exactSpread, hipStream_t st, unsigned long long* sens) {
     if (nFrames <= 0) return hipSuccess;
     const int nsig = chR ? 4 : 1;
     // dynamic LDS (doubles): FFT ping-pong [4H] + intensity spectrum [peakLast + 1].  The staged tables go into
@@ -1609,7 +1624,7 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
     const dim3 grid((unsigned)(nFrames * nsig));
 #define MRC_SMR_LAUNCH(EX, TY, THREADS, LG, MD)                                                                      \
     hipLaunchKernelGGL((smr_kernel<EX, TY, THREADS, LG, MD>), grid, dim3(THREADS), lds, st, S, nsig, (const TY*)chL, \
-                       (const TY*)chR, stride, offsets, lines, oscale, smr, thresh, bandPeak, msSwitch, lay)
+                       (const TY*)chR, stride, offsets, lines, oscale, smr, thresh, bandPeak, msSwitch, lay, sens)
 #ifndef MRC_SMR_THREADS                          // workgroup size for blocks of more than 128 lines
 #define MRC_SMR_THREADS 256
 #endif
@@ -1621,7 +1636,7 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
 #ifndef MRC_SMR_SHORT_LEAN                       // 1: short blocks of the hot paths run smr_short_kernel (a wavefront per unit)
 #define MRC_SMR_SHORT_LEAN 1
 #endif
-    if (MRC_SMR_SHORT_LEAN && isShort && !exactSpread && mode != 0 && kExpTab == 64 && S.nBands <= 32 && S.N == 256) {
+    if (MRC_SMR_SHORT_LEAN && isShort && !exactSpread && mode != 0 && kExpTab == 64 && S.nBands <= 32 && S.N == 256 && !sens) {
         const int64_t nUnits = nFrames * nsig;
         const int run = (int)std::min<int64_t>(16, std::max<int64_t>(1, nUnits / (kShortWaves * 4096)));
         const unsigned g = (unsigned)((nUnits + (int64_t)kShortWaves * run - 1) / ((int64_t)kShortWaves * run));
