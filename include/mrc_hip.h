@@ -475,7 +475,7 @@ int mrc_set_timing(mrc_handle* h, int enabled);
 #define MRC_OPT_CHAIN_THREADS 4
 /* MRC_OPT_SENSITIVITY = 1: every encode call on the handle also counts the integer decisions it took within a guard band of
  * floating-point rounding (see mrc_get_sensitivity); costs a pass over the intermediate results (~10 % of an encode).
- * = 2 (tests): the same with every guard band a million times wider, so that an ordinary corpus produces counts. */
+ * = 2 (tests): the same with every guard band 10^8 times wider, so that an ordinary corpus produces counts. */
 #define MRC_OPT_SENSITIVITY 5
 int mrc_set_option(mrc_handle* h, int option, int value);
 int mrc_get_option(mrc_handle* h, int option, int32_t* value);

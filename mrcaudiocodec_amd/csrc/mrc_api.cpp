@@ -162,7 +162,7 @@ int mrc_set_option(mrc_handle* h, int option, int value) {
                 MRC_HIP(h, h->sens.reserve(MRC_SENS_COUNT * sizeof(unsigned long long)));
                 MRC_HIP(h, hipMemset(h->sens.p, 0, MRC_SENS_COUNT * sizeof(unsigned long long)));
             }
-            const double scale = value == 2 ? 1e6 : 1.0;                 // slot 7: the guard scale the kernels read
+            const double scale = value == 2 ? 1e8 : 1.0;                 // slot 7: the guard scale the kernels read
             MRC_HIP(h, hipMemcpy(h->sens.as<unsigned long long>() + 7, &scale, sizeof scale, hipMemcpyHostToDevice));
         }
         h->sensOn = value != 0;
@@ -396,6 +396,21 @@ int encode_phase_a(mrc_handle* h, const DevShape& S, int64_t n, const void* chL,
 
 namespace {
 
+// event order on the stream: 0 | mdct | 1 | ms_switch | 2 | smr | 3 | bitalloc (few blocks: event preparation) | 4 | quantize
+// (few blocks: the scan kernel) | 5; reported order (mrc_get_kernel_ms): mdct, smr, ms_switch, bitalloc, quantize
+int collect_kernel_ms(mrc_handle* h) {
+    static const int from[5] = {0, 2, 1, 3, 4}, to[5] = {1, 3, 2, 4, 5};
+    for (int i = 0; i < 5; ++i) {
+        float ms = 0.f;
+        MRC_HIP(h, hipEventElapsedTime(&ms, h->ev[from[i]], h->ev[to[i]]));
+        h->kernelMs[i] = ms;
+    }
+    h->stageMs[0] = h->kernelMs[0];
+    h->stageMs[1] = h->kernelMs[1];
+    h->stageMs[2] = h->kernelMs[2] + h->kernelMs[3] + h->kernelMs[4];
+    return MRC_OK;
+}
+
 // The whole per-block path for n blocks of one shape, queued on `st`: phase A, then bit allocation -> scale factors +
 // mantissas.  Inputs and outputs are device pointers; `ws` holds the intermediate results and must not be shared with a
 // call running on another stream.
@@ -424,17 +439,7 @@ int encode_core(mrc_handle* h, const DevShape& S, int64_t n, const void* chL, co
     if (timing) {
         MRC_HIP(h, hipEventRecord(h->ev[5], st));
         MRC_HIP(h, hipEventSynchronize(h->ev[5]));
-        // event order on the stream: 0 | mdct | 1 | ms_switch | 2 | smr | 3 (re-recorded: | nothing | 3) | bitalloc | 4 | quantize | 5
-        // reported order (mrc_get_kernel_ms): mdct, smr, ms_switch, bitalloc, quantize
-        static const int from[5] = {0, 2, 1, 3, 4}, to[5] = {1, 3, 2, 4, 5};
-        for (int i = 0; i < 5; ++i) {
-            float ms = 0.f;
-            MRC_HIP(h, hipEventElapsedTime(&ms, h->ev[from[i]], h->ev[to[i]]));
-            h->kernelMs[i] = ms;
-        }
-        h->stageMs[0] = h->kernelMs[0];
-        h->stageMs[1] = h->kernelMs[1];
-        h->stageMs[2] = h->kernelMs[2] + h->kernelMs[3] + h->kernelMs[4];
+        MRC_TRY(collect_kernel_ms(h));
     }
     return MRC_OK;
 }
@@ -511,43 +516,87 @@ int encode_host(mrc_handle* h, int64_t n, int a, int b, const double* left, cons
     const size_t szMant = (size_t)n * nstream * S.halfN * sizeof(int32_t), szRes = (size_t)n * sizeof(int32_t);
     const size_t szLines = (size_t)n * nsig * S.halfN * sizeof(double);
     if (n <= kSmallBatch) {
-        // The per-block seam (pacfileThem.py:649,820 -> codecThem.py:205-278 hands over ONE block per call): every array in
-        // its own pageable copy cost more than the kernels (ten copies, each a staging round trip of the runtime).  Few
-        // blocks travel as ONE page-locked buffer each way: inputs packed by the host, outputs laid out back to back on the
-        // device -- [lines][scale][switch][sf][ba][mantissa][reservoir], each 16-byte aligned.
+        // The per-block seam (pacfileThem.py:649,820 -> codecThem.py:205-278 hands over ONE block per call).  Two things made
+        // such a call slow (0.45 ms per joint block in round 3): every array in its own pageable copy (ten staging round trips
+        // of the runtime), and the batch path's bit allocation -- one LANE per frame walking the greedy loop, ~135 us alone
+        // when there is one frame.  Few blocks therefore take
+        //   * ONE page-locked buffer each way and ONE device buffer laid out
+        //       [left][right][scan descriptor][items][item starts] [reservoir] [scale][switch][sf][ba][mantissa16][lines]
+        //     -- the copy in covers everything up to and including the reservoirs, the copy out everything from them on;
+        //   * phase A as always, then the CHAINED encode's back end: the allocation as a sorted event list
+        //     (chain_prep_kernel) and the scan kernel with every block as a stream of its own and Huffman pricing off, which
+        //     leaves exactly what JointEncodeChannels / EncodeSingleChannel return (codecThem.py:332,503: the allocation's
+        //     remainder as the reservoir; the savings are the caller's, 224,274).
         auto al = [](size_t v) { return (v + 15) & ~(size_t)15; };
-        const size_t oIn[4] = {0, al(inBytes), al(inBytes) + (joint ? al(inBytes) : 0), 0};
-        const size_t inTotal = oIn[2] + al(szRes);
-        MRC_HIP(h, h->pinIn.reserve(inTotal));
-        MRC_HIP(h, h->inL.reserve(inTotal));
+        const int nEv = (int)chain_events_per_block(S, joint), nTot = nstream * S.nBands;
+        const size_t szDesc = sizeof(ChainGroupDev), szItems = (size_t)n * sizeof(int32_t), szStart = (size_t)(n + 1) * sizeof(long long);
+        const size_t szMant16 = (size_t)n * nstream * S.halfN * sizeof(uint16_t);
+        const size_t oR = al(inBytes), oDesc = oR + (joint ? al(inBytes) : 0), oItems = oDesc + al(szDesc),
+                     oStart = oItems + al(szItems), oRes = oStart + al(szStart), oScale = oRes + al(szRes),
+                     oSw = oScale + al(szScale), oSf = oSw + al(joint ? szSw : 0), oBa = oSf + al(szBand), oMant = oBa + al(szBand),
+                     oLines = oMant + al(szMant16), total = oLines + al(szLines);
+        MRC_HIP(h, h->pinIn.reserve(oScale));
+        MRC_HIP(h, h->pinOut.reserve(total - oRes));
+        MRC_HIP(h, h->inL.reserve(total));
+        MRC_HIP(h, h->inAux.reserve((size_t)n * nEv * sizeof(unsigned)));
+        MRC_HIP(h, h->inAux2.reserve((size_t)n * (nEv + 1) * sizeof(unsigned)));
+        MRC_HIP(h, h->outB.reserve((size_t)n * nstream * sizeof(int32_t)));          // table ids (all 15: no pricing)
+        Workspace& ws = h->ws;
+        MRC_HIP(h, ws.smr.reserve((size_t)n * nsig * S.nBands * sizeof(double)));
+        MRC_HIP(h, ws.peak.reserve(alloc_workspace_bytes(S, n, joint)));
         char* pin = (char*)h->pinIn.p;
+        char* dev = (char*)h->inL.p;
         std::memcpy(pin, left, inBytes);
-        if (joint) std::memcpy(pin + oIn[1], right, inBytes);
-        if (reservoir_in) std::memcpy(pin + oIn[2], reservoir_in, szRes);
-        MRC_HIP(h, hipMemcpyAsync(h->inL.p, pin, reservoir_in ? inTotal : oIn[2], hipMemcpyHostToDevice, h->stream));
-        char* din = (char*)h->inL.p;
-        const size_t oLines = 0, oScale = al(mdct_out ? szLines : 0), oSw = oScale + al(szScale), oSf = oSw + al(joint ? szSw : 0),
-                     oBa = oSf + al(szBand), oMant = oBa + al(szBand), oRes = oMant + al(szMant), outTotal = oRes + al(szRes);
-        MRC_HIP(h, h->outA.reserve(outTotal));
-        if (!mdct_out) MRC_HIP(h, h->outG.reserve(szLines));
-        char* dout = (char*)h->outA.p;
-        MRC_TRY(mrc_dev_encode(h, a, b, n, (const double*)din, joint ? (const double*)(din + oIn[1]) : nullptr, S.N, nullptr,
-                               reservoir_in ? (const int32_t*)(din + oIn[2]) : nullptr, (int32_t*)(dout + oScale),
-                               (int32_t*)(dout + oSw), (int32_t*)(dout + oBa), (int32_t*)(dout + oSf),
-                               (int32_t*)(dout + oMant), (int32_t*)(dout + oRes),
-                               mdct_out ? (double*)(dout + oLines) : h->outG.as<double>(), h->stream));
-        MRC_HIP(h, h->pinOut.reserve(outTotal));
-        const size_t from = mdct_out ? 0 : oScale;               // (the lines only travel when asked for)
+        if (joint) std::memcpy(pin + oR, right, inBytes);
+        ChainGroupDev D{};
+        D.joint = joint; D.nb = S.nBands; D.nTot = nTot; D.M = S.halfN; D.K = S.maxMantBits - 1; D.nEv = nEv;
+        D.nScaleBits = S.nScaleBits; D.nstream = nstream;
+        D.maxN = 0;
+        for (int v : hs->bandN) if (v > D.maxN) D.maxN = v;
+        D.budgetMono = S.budgetMono; D.budgetJointPre = S.budgetJointPre; D.blkswA = S.blkswA; D.blkswB = S.blkswB;
+        D.bandOfLine = S.bandOfLine; D.bandN = S.bandN;
+        D.lines = (const double*)(dev + oLines); D.peak = ws.peak.as<double>(); D.oscale = (const int*)(dev + oScale);
+        D.ms = (const int*)(dev + oSw); D.ev = h->inAux.as<unsigned>(); D.pre = h->inAux2.as<unsigned>();
+        D.bitAlloc = (int*)(dev + oBa); D.scaleFactor = (int*)(dev + oSf); D.mant = (unsigned short*)(dev + oMant);
+        D.table = h->outB.as<int32_t>();
+        std::memcpy(pin + oDesc, &D, sizeof D);
+        for (int64_t i = 0; i < n; ++i) {
+            reinterpret_cast<int32_t*>(pin + oItems)[i] = (int32_t)i;                  // group 0, block i
+            reinterpret_cast<long long*>(pin + oStart)[i] = i;
+            reinterpret_cast<int32_t*>(pin + oRes)[i] = reservoir_in ? reservoir_in[i] : 0;
+        }
+        reinterpret_cast<long long*>(pin + oStart)[n] = n;
+        hipStream_t st = h->stream;
+        MRC_HIP(h, hipMemcpyAsync(dev, pin, oScale, hipMemcpyHostToDevice, st));
+        const bool timing = h->timing;
+        MRC_TRY(encode_phase_a(h, S, n, dev, joint ? dev + oR : nullptr, kSampleF64, S.N, nullptr, (double*)(dev + oLines),
+                               (int32_t*)(dev + oScale), joint ? (int32_t*)(dev + oSw) : nullptr, ws.smr.as<double>(),
+                               ws.peak.as<double>(), st, timing));
+        MRC_HIP(h, launch_chain_prep(S, joint, n, ws.smr.as<double>(), joint ? (const int*)(dev + oSw) : nullptr,
+                                     h->inAux.as<unsigned>(), h->inAux2.as<unsigned>(), 0, st));
+        if (timing) MRC_HIP(h, hipEventRecord(h->ev[4], st));
+        MRC_HIP(h, launch_chain_phase_b(n, (const ChainGroupDev*)(dev + oDesc), (const int*)(dev + oItems),
+                                        (const long long*)(dev + oStart), (int*)(dev + oRes), nullptr, 0, h->chainThreads, st));
+        if (timing) MRC_HIP(h, hipEventRecord(h->ev[5], st));
+        if (h->sensOn)
+            MRC_HIP(h, launch_sensitivity(S, n, joint, (const double*)(dev + oLines), (const int*)(dev + oScale),
+                                          ws.smr.as<double>(), ws.peak.as<double>(), joint ? (const int*)(dev + oSw) : nullptr,
+                                          (const int*)(dev + oBa), (const int*)(dev + oSf), h->sens.as<unsigned long long>(),
+                                          nullptr, st));
         char* pout = (char*)h->pinOut.p;
-        MRC_HIP(h, hipMemcpyAsync(pout + from, dout + from, outTotal - from, hipMemcpyDeviceToHost, h->stream));
-        MRC_HIP(h, hipStreamSynchronize(h->stream));
-        if (mdct_out) std::memcpy(mdct_out, pout + oLines, szLines);
-        std::memcpy(overall_scale, pout + oScale, szScale);
-        if (joint) std::memcpy(ms_switch, pout + oSw, szSw);
-        std::memcpy(scale_factor, pout + oSf, szBand);
-        std::memcpy(bit_alloc, pout + oBa, szBand);
-        std::memcpy(mantissa, pout + oMant, szMant);
-        std::memcpy(reservoir_out, pout + oRes, szRes);
+        const size_t outBytes = (mdct_out ? total : oLines) - oRes;                     // (the lines only travel when asked for)
+        MRC_HIP(h, hipMemcpyAsync(pout, dev + oRes, outBytes, hipMemcpyDeviceToHost, st));
+        MRC_HIP(h, hipStreamSynchronize(st));
+        if (timing) MRC_TRY(collect_kernel_ms(h));
+        const char* o = pout - oRes;                                                    // (same offsets as on the device)
+        std::memcpy(reservoir_out, o + oRes, szRes);
+        std::memcpy(overall_scale, o + oScale, szScale);
+        if (joint) std::memcpy(ms_switch, o + oSw, szSw);
+        std::memcpy(scale_factor, o + oSf, szBand);
+        std::memcpy(bit_alloc, o + oBa, szBand);
+        const uint16_t* m16 = reinterpret_cast<const uint16_t*>(o + oMant);
+        for (size_t i = 0; i < (size_t)n * nstream * S.halfN; ++i) mantissa[i] = (int32_t)m16[i];
+        if (mdct_out) std::memcpy(mdct_out, o + oLines, szLines);
         return MRC_OK;
     }
     MRC_TRY(s.up(h->inL, left, inBytes));

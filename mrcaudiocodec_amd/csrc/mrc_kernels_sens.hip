@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void sensitivity_kernel(DevShape S, int joint,
     __shared__ unsigned sCount[3];
     const int tid = threadIdx.x;
     const int64_t f = blockIdx.x;
-    const double gs = __longlong_as_double((long long)sens[7]);       // guard scale: 1, or 1e6 in the tests' loose mode
+    const double gs = __longlong_as_double((long long)sens[7]);       // guard scale: 1, or 1e8 in the tests' loose mode
     const int nb = S.nBands, M = S.halfN, nsig = joint ? 4 : 1, nstream = joint ? 2 : 1, nTot = nstream * nb;
     const double* X = lines + f * nsig * M;
     if (tid < kMaxBands) { sD[tid] = 0.0; sS[tid] = 0.0; }

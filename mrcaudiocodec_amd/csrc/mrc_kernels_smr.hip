@@ -881,7 +881,7 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     if (sens) {
         // MRC_OPT_SENSITIVITY: strict comparisons of psychoac.py:162 that a relative change of kPeakGuard in a bin would turn
         // round (a bin within the guard of a neighbour it has to beat, while it does not clearly lose against the other one)
-        const double kPeakGuard = 1e-11 * __longlong_as_double((long long)sens[7]);    // (sens[7]: guard scale, 1 or 1e6)
+        const double kPeakGuard = 1e-11 * __longlong_as_double((long long)sens[7]);    // (sens[7]: guard scale, 1 or 1e8)
         int near = 0;
         for (int p = p0; p < p1; ++p) {
             const double c = xi[p], l = xi[p - 1], r = xi[p + 1];

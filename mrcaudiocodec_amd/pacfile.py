@@ -68,6 +68,13 @@ def header(cfg, n_channels, num_samples):
     return out[:n.value].tobytes()
 
 
+_BOUNDS = {}                    # mrc_pack_bound per (shape, channels, codec parameters): it walks a band table per call
+# mrc_pack_blocks_ex with untyped pointer arguments (the typed prototype of _lib makes every array go through a cast)
+_pack_blocks_ex = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                              C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p,
+                              C.c_void_p, C.c_void_p)(("mrc_pack_blocks_ex", lib))
+
+
 def _pack(cfg, a, b, joint, overall_scale, ms_switch, scale_factor, bit_alloc, mantissa, use_huffman, huff_table):
     """mrc_pack_blocks_ex: the mantissa plane goes in as it is -- int32, or the uint16 codes the PCM16 / mantissa16
     encode paths deliver (an int16 view of them is taken as uint16)."""
@@ -82,17 +89,22 @@ def _pack(cfg, a, b, joint, overall_scale, ms_switch, scale_factor, bit_alloc, m
         m, fmt = _i32(m), 0
     sw = None if ms_switch is None else _i32(ms_switch)
     ht = None if huff_table is None else _i32(huff_table).reshape(n, nch)
-    bound = lib.mrc_pack_bound(C.byref(cfg), int(a), int(b), nch, int(joint))
-    if bound < 0:
-        raise MrcError("mrc_pack_bound failed (%d)" % bound)
+    key = (int(a), int(b), nch, int(joint), cfg.n_mdct_lines, cfg.n_scale_bits, cfg.n_mant_size_bits, cfg.blksw_bits_a,
+           cfg.blksw_bits_b, cfg.sample_rate)
+    bound = _BOUNDS.get(key)
+    if bound is None:
+        bound = lib.mrc_pack_bound(C.byref(cfg), int(a), int(b), nch, int(joint))
+        if bound < 0:
+            raise MrcError("mrc_pack_bound failed (%d)" % bound)
+        _BOUNDS[key] = bound
     out = np.empty(max(1, n * bound), dtype=np.uint8)          # every byte up to offs[n] is written by the packer
-    offs = np.zeros(n + 1, dtype=np.int64)
-    table = np.zeros((n, nch), dtype=np.int32) if ht is None else None
-    saved = np.zeros((n, nch), dtype=np.int32) if ht is None else None
-    p32 = lambda arr: None if arr is None else arr.ctypes.data_as(_i32p)
-    _check(lib.mrc_pack_blocks_ex(C.byref(cfg), n, nch, int(a), int(b), int(joint), int(bool(use_huffman)), p32(ht), p32(osc),
-                                  p32(sw), p32(sf), p32(ba), m.ctypes.data_as(C.c_void_p), fmt, out.ctypes.data_as(_u8p),
-                                  out.size, offs.ctypes.data_as(_i64p), p32(table), p32(saved)), "mrc_pack_blocks_ex")
+    offs = np.empty(n + 1, dtype=np.int64)
+    table = np.empty((n, nch), dtype=np.int32) if ht is None else None
+    saved = np.empty((n, nch), dtype=np.int32) if ht is None else None
+    ptr = lambda arr: None if arr is None else C.c_void_p(arr.ctypes.data)      # (cheaper than data_as with a pointer type)
+    rc = _pack_blocks_ex(C.byref(cfg), n, nch, int(a), int(b), int(joint), int(bool(use_huffman)), ptr(ht), ptr(osc), ptr(sw),
+                         ptr(sf), ptr(ba), ptr(m), fmt, ptr(out), out.size, ptr(offs), ptr(table), ptr(saved))
+    _check(rc, "mrc_pack_blocks_ex")
     return out[:offs[n]], offs, (ht if ht is not None else table), saved
 
 

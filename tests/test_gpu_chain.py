@@ -106,10 +106,10 @@ _LONG_SWITCHED = {}
 
 
 def _long_switched():
-    """a block-switched stereo stream of 600 hops (all four block shapes, > 256 items: the scan's item ring refills while the
+    """a block-switched stereo stream of 601 hops (all four block shapes, > 256 items: the scan's item ring refills while the
     shapes change) and its bytes from the block-at-a-time loop; built once for the parametrised test below"""
     if not _LONG_SWITCHED:
-        stream, shapes = _switching_stream(hops=600, seed=9)
+        stream, shapes = _switching_stream(hops=601, seed=9)
         _LONG_SWITCHED.update(stream=stream, shapes=shapes)
     return _LONG_SWITCHED
 

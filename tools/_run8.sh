@@ -1,0 +1,2 @@
+cd $GRAFT_REPO_ROOT
+timeout -k 10 600 python -m pytest tests/test_gpu_sensitivity.py -m gpu -x -q 2>&1 | tail -15
