@@ -876,19 +876,34 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     const int per = (nCand + NT - 1) / NT;
     const int p0 = 1 + tid * per;
     const int p1 = min(p0 + per, last - 1);
+    // a thread's candidate bins and their neighbours are read ONCE (per + 2 values); the peak flags serve the count, the
+    // ordered compaction behind the barrier and (MRC_OPT_SENSITIVITY) the near-tie count
+    constexpr int kPerMax = 4;                           // long block: 4 candidates per thread, transition: 2, short: 1
     int mine = 0;
-    for (int p = p0; p < p1; ++p) mine += (xi[p] > xi[p - 1] && xi[p] > xi[p + 1]) ? 1 : 0;
-    if (sens) {
-        // MRC_OPT_SENSITIVITY: strict comparisons of psychoac.py:162 that a relative change of kPeakGuard in a bin would turn
-        // round (a bin within the guard of a neighbour it has to beat, while it does not clearly lose against the other one)
-        const double kPeakGuard = 1e-11 * __longlong_as_double((long long)sens[7]);    // (sens[7]: guard scale, 1 or 1e8)
-        int near = 0;
-        for (int p = p0; p < p1; ++p) {
-            const double c = xi[p], l = xi[p - 1], r = xi[p + 1];
-            const bool nl = fabs(c - l) <= kPeakGuard * c, nr = fabs(c - r) <= kPeakGuard * c;
-            near += ((nl && (c > r || nr)) || (nr && (c > l || nl))) ? 1 : 0;
+    unsigned flags = 0;
+    if (per <= kPerMax) {
+        double v[kPerMax + 2];
+#pragma unroll
+        for (int j = 0; j < kPerMax + 2; ++j) v[j] = xi[min(p0 - 1 + j, last - 1)];
+#pragma unroll
+        for (int j = 0; j < kPerMax; ++j)
+            if (p0 + j < p1 && v[j + 1] > v[j] && v[j + 1] > v[j + 2]) flags |= 1u << j;
+        mine = __popc(flags);
+        if (sens) {
+            // MRC_OPT_SENSITIVITY: strict comparisons of psychoac.py:162 that a relative change of kPeakGuard in a bin would
+            // turn round (a bin within the guard of a neighbour it has to beat, while it does not clearly lose against the other)
+            const double kPeakGuard = 1e-11 * __longlong_as_double((long long)sens[7]);    // (sens[7]: guard scale, 1 or 1e8)
+            int near = 0;
+#pragma unroll
+            for (int j = 0; j < kPerMax; ++j) {
+                const double c = v[j + 1], l = v[j], r = v[j + 2];
+                const bool nl = fabs(c - l) <= kPeakGuard * c, nr = fabs(c - r) <= kPeakGuard * c;
+                near += (p0 + j < p1 && ((nl && (c > r || nr)) || (nr && (c > l || nl)))) ? 1 : 0;
+            }
+            if (near) atomicAdd(&sens[3], (unsigned long long)near);
         }
-        if (near) atomicAdd(&sens[3], (unsigned long long)near);
+    } else {
+        for (int p = p0; p < p1; ++p) mine += (xi[p] > xi[p - 1] && xi[p] > xi[p + 1]) ? 1 : 0;
     }
     const int incl = wave_incl_scan(mine, lane);
     if (lane == kWave - 1) waveCnt[wave] = incl;
@@ -901,12 +916,18 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     }
     // compact the peak bins first (ordered), then one masker per thread: the transcendental-heavy
     // table entry is computed by full waves instead of the few lanes that happen to own a peak
-    for (int p = p0; p < p1; ++p)
-        if (xi[p] > xi[p - 1] && xi[p] > xi[p + 1]) {
-            pkBin[before++] = (short)p;
-        }
-    if (!EXACT)
-        for (int k = tid; k <= M; k += NT) { cntArr[k] = 0; nUpArr[k] = 0; }
+    if (per <= kPerMax) {
+#pragma unroll
+        for (int j = 0; j < kPerMax; ++j)
+            if ((flags >> j) & 1u) pkBin[before++] = (short)(p0 + j);
+    } else {
+        for (int p = p0; p < p1; ++p)
+            if (xi[p] > xi[p - 1] && xi[p] > xi[p + 1]) pkBin[before++] = (short)p;
+    }
+    if (!EXACT) {                                        // the two count histograms (adjacent: 2 (M + 2) shorts), eight bytes a store
+        unsigned long long* z = reinterpret_cast<unsigned long long*>(cntArr);
+        for (int k = tid; k < (M + 2) / 2; k += NT) z[k] = 0ull;
+    }
     __syncthreads();
     MRC_PHASE(3); MRC_STOP(3);
     double slLo = 1e300, slHi = -1e300;                 // this thread's maskers: range of the upper slope
