@@ -440,6 +440,24 @@ def main():
         }
 
     Fx = min(args.extra_frames, F)                      # batch of the other configurations
+    if not args.skip_extras and world == 1:
+        # ---- the sensitivity certificate of one headline step (outside the timed region): how many of its integer decisions
+        # lay within a guard band of floating-point rounding (mrc_get_sensitivity) -- what "bit-exact" means at this size
+        enc.h.set_option(5, 1)
+        enc.h.sensitivity()
+        t0 = time.perf_counter()
+        enc.encode_long(pcm, None, F, mantissa16=True)
+        torch.cuda.synchronize(device)
+        t_sens = time.perf_counter() - t0
+        cert = enc.h.sensitivity()
+        enc.h.set_option(5, 0)
+        cert["decisions_near_an_edge"] = sum(cert[k] for k in ("quantiser_edges", "bitalloc_near_ties", "ms_switch_near_threshold",
+                                                               "peak_near_ties"))
+        cert["ms_with_counting"] = round(t_sens * 1e3, 3)
+        cert["guards"] = ("lines 4e-13 of the scaled block peak at a mantissa / scale-factor edge; SMR pairs 1e-9 dB from a multiple "
+                          "of 6 dB; M/S test 1e-12 (relative) from its 0.8 threshold; spectral bins 1e-11 (relative) from a "
+                          "neighbour they must beat (include/mrc_hip.h, MRC_SENS_*)")
+        line["sensitivity"] = cert
     if not args.skip_extras:
         # ---- the float64-in / int32-out layout round 1 measured (continuity)
         p64 = pcm[:(Fx + 1) * HOP].double()

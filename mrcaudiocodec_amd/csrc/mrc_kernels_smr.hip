@@ -425,6 +425,21 @@ __host__ __device__ constexpr SmrLds smr_layout(int H, int M, int last, int* tot
     return lay;
 }
 
+// Slope nodes: the most maskers a block of DIM lines can take through them.  Rows of kNodeCols doubles for every fourth
+// masker (+ row 0) lie between the per-line counts and the log10 table (where the peak bins and the Bark grid were); the masker
+// table (4 P) and the in-band prefix sums (2 (P + 1)) share the first FFT buffer with the band keys and the 2^x table (96).
+__host__ __device__ constexpr int node_max_maskers(int DIM) {
+    const SmrLds lay = smr_layout(DIM, DIM, DIM - 100, nullptr);
+    const int qStart = 2 * DIM + (2 * (DIM + 2) * 2) / 8;               // behind cnt / nUp ((DIM + 2) uint16 each)
+    if (lay.logOff <= qStart || lay.logOff >= 4 * DIM) return 0;        // (the log10 table is not behind the rows in this layout)
+    const int rows = (lay.logOff - qStart) / 18;
+    const int byRows = (rows - 1) * 4, byTable = (2 * DIM - 96 - 2) / 6, bySeg = 3 * 26 * 4 - 4;
+    int m = byRows < byTable ? byRows : byTable;
+    m = m < bySeg ? m : bySeg;
+    return m < 0 ? 0 : m;
+}
+static_assert(node_max_maskers(1024) == 308, "long block: 78 rows");
+
 // inclusive prefix sum over the 64 lanes, in registers: Kogge-Stone inside each 16-lane row with DPP row shifts (lanes
 // that would read across the row's start get 0), then the row totals are passed on with row_bcast:15 / row_bcast:31
 template <int CTRL, int ROW_MASK>
@@ -477,7 +492,7 @@ __device__ __forceinline__ double wave_incl_scan(double v) {
 // Lambda_m = sum_r |lambda_r| (column R + 1).  A chunk one of whose lines has  bound > kNodeTol x (its total masked
 // intensity)  is evaluated again by the sorted sweep (upper_cold): lines that live on distant loud maskers (beyond a cliff in
 // the spectrum) are where the interpolation is weakest.  Frames whose slope range is too wide for R nodes, with fewer than
-// kNodeMinMaskers or more than kNodeMaxMaskers maskers take the sorted sweep as a whole.
+// kNodeMinMaskers or more than node_max_maskers(DIM) maskers take the sorted sweep as a whole.
 constexpr int kNodeR = 16;
 constexpr int kNodeMargin = 1;
 constexpr int kNodeCols = kNodeR + 2;
@@ -485,7 +500,6 @@ constexpr double kNodeHMax = 0.22;                   // node spacing, bit per Ba
 constexpr double kNodeHMin = 1e-3;
 constexpr int kNodeMinMaskers = 32;
 constexpr int kNodeC = 4;                            // maskers per row of the prefix sums (a quad of lanes)
-constexpr int kNodeMaxMaskers = 308;                 // 78 rows fit in front of the log10 table (and 4 P + 2 (P + 1) <= 2048 - 96)
 constexpr int kNodeSeg = 26;                         // rows per lane in the scan over the rows (three lanes per column)
 constexpr double kNodeTol = 1e-13;                   // accepted bound on the error of a line's masked intensity (relative)
 constexpr double kNodeRoundEps = 8.0 * 0x1p-53;      // K eps: K = 8 covers the measured rounding (tools/rank_proto2.py: <= 1.1)
@@ -1043,11 +1057,9 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         const int waveU = __builtin_amdgcn_readfirstlane(wave);          // (uniform: chunk indices stay in SGPRs)
         // ---- which evaluation of the upper-side sum the frame takes (wave-uniform): slope nodes (see kNodeR) when its
         // maskers are many and their slopes lie within reach of R nodes, else the sorted sweep.  Long blocks only.
-        constexpr bool kNodes = LONG && NT == 256;
-        static_assert(!kNodes || (2 * 1024 + (2 * 1026 * 2) / 8 + ((kNodeMaxMaskers + kNodeC - 1) / kNodeC + 1) * kNodeCols <=
-                                  smr_layout(1024, 1024, 924, nullptr).logOff),
-                      "node rows do not fit between the per-line counts and the log10 table");
-        static_assert(3 * kNodeSeg >= (kNodeMaxMaskers + kNodeC - 1) / kNodeC, "node_scan: three lanes per column cover the rows");
+        constexpr bool kNodes = (DIM == 1024 || DIM == 576) && NT == 256;      // (576: 156 of a transition block's <= 237 maskers)
+        constexpr int kNodeMaxMaskers = kNodes ? node_max_maskers(DIM ? DIM : 1024) : 0;
+        static_assert(!kNodes || kNodeMaxMaskers >= 128, "slope nodes: too few rows for this block shape");
         [[maybe_unused]] double nodeH = 0.0, nodeS0 = 0.0;               // node spacing / shallowest node (1/TAB bit per Bark)
         bool useNodes = false;
         if constexpr (kNodes) {
