@@ -1215,19 +1215,26 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
 #ifndef MRC_PROFILE_NODESKIP                     // profiling aid (wrong results): 1 no node terms, 2 no remainder pairs, 4 no Horner
 #define MRC_PROFILE_NODESKIP 0
 #endif
-        if constexpr (kNodes) {
-            if (useNodes && !(MRC_PROFILE_NODESKIP & 1)) node_terms();
-        }
-        // four independent scans, dealt to the workgroup's waves (4 waves: one each; 2 waves: two each)
-        for (int task = waveU; task < 4; task += NT / kWave) {
-            if (task == 0) scan_sc();
-            else if (task == 1) scan_pi();
-            else scan_counts(task == 2 ? cntArr : nUpArr);
-        }
+        bool scansDone = false;
         if constexpr (kNodes) {
             if (useNodes) {                              // (workgroup-uniform)
+                // the node terms by every wave, then -- behind one barrier -- the scan over their rows (one wave) BESIDE the
+                // other scans on the other waves
+                if (!(MRC_PROFILE_NODESKIP & 1)) node_terms();
                 __syncthreads();
-                if (waveU == 0 && !(MRC_PROFILE_NODESKIP & 1)) node_scan();
+                if (waveU == 0) { if (!(MRC_PROFILE_NODESKIP & 1)) node_scan(); }
+                else if (waveU == 1) scan_pi();
+                else if (waveU == 2) { scan_counts(cntArr); scan_sc(); }
+                else scan_counts(nUpArr);
+                scansDone = true;
+            }
+        }
+        if (!scansDone) {
+            // four independent scans, dealt to the workgroup's waves (4 waves: one each; 2 waves: two each)
+            for (int task = waveU; task < 4; task += NT / kWave) {
+                if (task == 0) scan_sc();
+                else if (task == 1) scan_pi();
+                else scan_counts(task == 2 ? cntArr : nUpArr);
             }
         }
         __syncthreads();
