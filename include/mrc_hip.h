@@ -477,6 +477,12 @@ int mrc_set_timing(mrc_handle* h, int enabled);
  * floating-point rounding (see mrc_get_sensitivity); costs a pass over the intermediate results (~10 % of an encode).
  * = 2 (tests): the same with every guard band 10^8 times wider, so that an ordinary corpus produces counts. */
 #define MRC_OPT_SENSITIVITY 5
+/* MRC_OPT_CHAIN_SLAB_BLOCKS = n: the chained encode (mrc_encode_chained_stream*_pac, mrc_dev_encode_chained_pac) cuts a call
+ * into slabs of at most n blocks -- whole streams while they fit, a longer stream alone in consecutive time slabs, the bit
+ * reservoir carried from slab to slab -- so that the device memory of a call is bounded by the slab (~45 KB per joint long
+ * block + the slab's worst-case output, 13 KB per block) whatever the length of the file.  Default 65 536 (~3.8 GB);
+ * 0: one slab.  The bytes do not depend on it. */
+#define MRC_OPT_CHAIN_SLAB_BLOCKS 6
 int mrc_set_option(mrc_handle* h, int option, int value);
 int mrc_get_option(mrc_handle* h, int option, int32_t* value);
 int mrc_get_stage_ms(mrc_handle* h, double* ms /*[3]*/);

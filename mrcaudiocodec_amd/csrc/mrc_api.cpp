@@ -168,6 +168,11 @@ int mrc_set_option(mrc_handle* h, int option, int value) {
         h->sensOn = value != 0;
         return MRC_OK;
     }
+    if (option == MRC_OPT_CHAIN_SLAB_BLOCKS) {
+        if (value < 0) return fail(h, MRC_ERR_INVALID, "mrc_set_option: MRC_OPT_CHAIN_SLAB_BLOCKS takes a block count (0: no slabs)");
+        h->chainSlabBlocks = value;
+        return MRC_OK;
+    }
     if (option == MRC_OPT_CHAIN_THREADS) {
         if (value != 0 && value != 256 && value != 512 && value != 1024) return fail(h, MRC_ERR_INVALID, "mrc_set_option: MRC_OPT_CHAIN_THREADS takes 0, 256, 512 or 1024");
         h->chainThreads = value;
@@ -184,6 +189,7 @@ int mrc_get_option(mrc_handle* h, int option, int32_t* value) {
         case MRC_OPT_CHAIN_FORCE_REPAIR: *value = h->chainForceFallback ? 1 : 0; return MRC_OK;
         case MRC_OPT_CHAIN_THREADS: *value = h->chainThreads; return MRC_OK;
         case MRC_OPT_SENSITIVITY: *value = h->sensOn ? 1 : 0; return MRC_OK;
+        case MRC_OPT_CHAIN_SLAB_BLOCKS: *value = (int32_t)h->chainSlabBlocks; return MRC_OK;
         default: return fail(h, MRC_ERR_INVALID, "mrc_get_option: unknown option");
     }
 }

@@ -62,12 +62,18 @@ int64_t mrc_chain_out_bound(mrc_handle* h, int64_t n_streams, const int64_t* blo
     return total;
 }
 
-int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm_left, const void* pcm_right,
-                               int sample_format, int64_t stream_stride, const int64_t* block_start, const int64_t* block_offset,
-                               const int32_t* block_a, const int32_t* block_b, const int32_t* reservoir_in,
-                               int use_huffman, int with_flush, const uint32_t* num_samples, uint8_t* out, int64_t out_cap,
-                               int64_t* stream_byte_offset, int64_t* item_byte_offset, int32_t* reservoir_out,
-                               int32_t* reservoir_trace, int64_t* total_bytes, void* stream) {
+}  // extern "C"
+
+namespace {
+
+// One SLAB of a chained encode: all of the streams [0, n_streams) handed over, every buffer sized for exactly these blocks
+// (the entry points below cut a call into slabs).
+int chained_core(mrc_handle* h, int64_t n_streams, const void* pcm_left, const void* pcm_right,
+                 int sample_format, int64_t stream_stride, const int64_t* block_start, const int64_t* block_offset,
+                 const int32_t* block_a, const int32_t* block_b, const int32_t* reservoir_in,
+                 int use_huffman, int with_flush, const uint32_t* num_samples, uint8_t* out, int64_t out_cap,
+                 int64_t* stream_byte_offset, int64_t* item_byte_offset, int32_t* reservoir_out,
+                 int32_t* reservoir_trace, int64_t* total_bytes, void* stream) {
     if (!h || n_streams < 0 || !pcm_left || !pcm_right || stream_stride <= 0 || !block_start || !block_offset ||
         !block_a || !block_b || !out || out_cap < 0 || !stream_byte_offset || !total_bytes ||
         (sample_format != MRC_SAMPLES_F64 && sample_format != MRC_SAMPLES_PCM16))
@@ -343,6 +349,137 @@ int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm
     return MRC_OK;
 }
 
+// ---- slabs (round 4).  Phase A keeps ~45 KB of device memory per joint long block (the MDCT lines of four signals, SMRs,
+// events, outputs) and the worst-case output bound is 13 KB per block: a call over a 2^18-hop file would hold 18 GB.  A call is
+// therefore cut into SLABS of at most h->chainSlabBlocks blocks, each a chained_core of its own whose buffers are reused by
+// the next: whole streams while they fit (their files stay contiguous in the output), a stream longer than a slab alone in
+// consecutive TIME slabs -- the reservoir goes from slab to slab as it goes from block to block (codecThem.py:274,503), the
+// header travels with the first slab, Close()'s blocks with the last.  `sink` receives each slab's bytes.
+struct Slab { int64_t s0, ns; int64_t i0, i1; bool first, last, timeSlab; };
+
+std::vector<Slab> plan_slabs(int64_t n_streams, const int64_t* block_start, int64_t cap) {
+    std::vector<Slab> v;
+    int64_t s = 0;
+    while (s < n_streams) {
+        const int64_t nb = block_start[s + 1] - block_start[s];
+        if (nb > cap) {                                  // one long stream: time slabs
+            for (int64_t i = block_start[s]; i < block_start[s + 1]; i += cap) {
+                const int64_t e = std::min<int64_t>(i + cap, block_start[s + 1]);
+                v.push_back({s, 1, i, e, i == block_start[s], e == block_start[s + 1], true});
+            }
+            ++s;
+            continue;
+        }
+        int64_t e = s, blocks = 0;
+        while (e < n_streams && block_start[e + 1] - block_start[e] <= cap && blocks + (block_start[e + 1] - block_start[e]) <= cap) {
+            blocks += block_start[e + 1] - block_start[e];
+            ++e;
+        }
+        v.push_back({s, e - s, block_start[s], block_start[e], true, true, false});
+        s = e;
+    }
+    return v;
+}
+
+// sink(slab bytes are at `buf` on the device, n of them, they belong at byte `at` of the call's output) -> status
+template <class Sink>
+int chained_slabs(mrc_handle* h, int64_t n_streams, const void* pcm_left, const void* pcm_right, int sample_format,
+                  int64_t stream_stride, const int64_t* block_start, const int64_t* block_offset, const int32_t* block_a,
+                  const int32_t* block_b, const int32_t* reservoir_in, int use_huffman, int with_flush,
+                  const uint32_t* num_samples, int64_t out_cap, int64_t* stream_byte_offset, int64_t* item_byte_offset,
+                  int32_t* reservoir_out, int32_t* reservoir_trace, int64_t* total_bytes, void* stream,
+                  uint8_t* direct_out /* device buffer of out_cap bytes to write into in place, or null: C.out per slab */,
+                  Sink sink) {
+    if (!h || n_streams < 0 || !block_start || !stream_byte_offset || !total_bytes)
+        return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: bad argument");
+    *total_bytes = 0;
+    stream_byte_offset[0] = 0;
+    if (n_streams == 0) return MRC_OK;
+    for (int64_t s = 0; s < n_streams; ++s)
+        if (block_start[s + 1] <= block_start[s]) return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: every stream needs at least one block");
+    const size_t sampleBytes = sample_format == MRC_SAMPLES_PCM16 ? sizeof(int16_t) : sizeof(double);
+    const std::vector<Slab> slabs = plan_slabs(n_streams, block_start, h->chainSlabBlocks > 0 ? h->chainSlabBlocks : (int64_t)1 << 40);
+    ChainBufs& C = h->chain;
+    C.lastTotal = -1;
+    int64_t written = 0, itemBase = 0;
+    bool overflow = false;
+    double ms[4] = {0, 0, 0, 0};
+    std::vector<int64_t> sOff, iOff;
+    int32_t carry = 0;
+    for (const Slab& sl : slabs) {
+        const char* pl = (const char*)pcm_left + (size_t)sl.s0 * stream_stride * sampleBytes;
+        const char* pr = (const char*)pcm_right + (size_t)sl.s0 * stream_stride * sampleBytes;
+        const int64_t bs2[2] = {sl.i0, sl.i1};
+        const int64_t* bs = sl.timeSlab ? bs2 : block_start + sl.s0;
+        const int flush = with_flush && sl.last;
+        const uint32_t* nsamp = (num_samples && sl.first) ? num_samples + sl.s0 : nullptr;
+        const int32_t* resIn = sl.timeSlab ? (sl.first ? (reservoir_in ? reservoir_in + sl.s0 : nullptr) : &carry)
+                                           : (reservoir_in ? reservoir_in + sl.s0 : nullptr);
+        const int64_t nItems = (sl.i1 - sl.i0) + (flush ? 2 * sl.ns : 0);
+        sOff.assign((size_t)sl.ns + 1, 0);
+        if (item_byte_offset) iOff.assign((size_t)nItems + 1, 0);
+        int64_t slabTotal = 0;
+        uint8_t* dst;
+        int64_t cap;
+        if (direct_out && !overflow) { dst = direct_out + written; cap = out_cap - written; }
+        else {
+            const int64_t bound = mrc_chain_out_bound(h, sl.ns, bs, block_a, block_b, flush, nsamp != nullptr);
+            if (bound < 0) return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: block shape out of range");
+            MRC_HIP(h, hipSetDevice(h->device));
+            MRC_HIP(h, C.out.reserve((size_t)bound + 1));
+            dst = C.out.as<uint8_t>(); cap = bound;
+        }
+        int32_t resOutSlab[1] = {0};
+        int rc = chained_core(h, sl.ns, pl, pr, sample_format, stream_stride, bs, block_offset, block_a, block_b, resIn,
+                              use_huffman, flush, nsamp, dst, cap, sOff.data(), item_byte_offset ? iOff.data() : nullptr,
+                              sl.timeSlab ? resOutSlab : (reservoir_out ? reservoir_out + sl.s0 : nullptr),
+                              reservoir_trace ? reservoir_trace + itemBase : nullptr, &slabTotal, stream);
+        if (rc == MRC_ERR_NOMEM && direct_out) overflow = true;          // the caller's buffer is full: sizes only from here on
+        else if (rc != MRC_OK) return rc;
+        for (int i = 0; i < 4; ++i) ms[i] += h->chainMs[i];
+        if (sl.timeSlab) {
+            carry = resOutSlab[0];
+            if (sl.first) stream_byte_offset[sl.s0] = written + sOff[0];
+            if (sl.last) { stream_byte_offset[sl.s0 + 1] = written + slabTotal; if (reservoir_out) reservoir_out[sl.s0] = carry; }
+        } else {
+            for (int64_t s = 0; s <= sl.ns; ++s) stream_byte_offset[sl.s0 + s] = written + sOff[(size_t)s];
+        }
+        if (item_byte_offset)
+            for (int64_t i = 0; i <= nItems; ++i) item_byte_offset[itemBase + i] = written + iOff[(size_t)i];
+        if (!direct_out && !overflow) {
+            if (written + slabTotal > out_cap) overflow = true;
+            else MRC_TRY(sink(dst, slabTotal, written));
+        }
+        written += slabTotal;
+        itemBase += nItems;
+    }
+    for (int i = 0; i < 4; ++i) h->chainMs[i] = ms[i];
+    *total_bytes = written;
+    stream_byte_offset[n_streams] = written;
+    if (slabs.size() == 1 && !direct_out) C.lastTotal = written;         // (one slab: its bytes are all in C.out, mrc_chain_fetch_output)
+    if (overflow || written > out_cap) return fail(h, MRC_ERR_NOMEM, "mrc_encode_chained: out_cap too small (see total_bytes)");
+    return MRC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mrc_dev_encode_chained_pac(mrc_handle* h, int64_t n_streams, const void* pcm_left, const void* pcm_right,
+                               int sample_format, int64_t stream_stride, const int64_t* block_start, const int64_t* block_offset,
+                               const int32_t* block_a, const int32_t* block_b, const int32_t* reservoir_in,
+                               int use_huffman, int with_flush, const uint32_t* num_samples, uint8_t* out, int64_t out_cap,
+                               int64_t* stream_byte_offset, int64_t* item_byte_offset, int32_t* reservoir_out,
+                               int32_t* reservoir_trace, int64_t* total_bytes, void* stream) {
+    if (!h || !pcm_left || !pcm_right || stream_stride <= 0 || !block_offset || !block_a || !block_b || !out || out_cap < 0 ||
+        (sample_format != MRC_SAMPLES_F64 && sample_format != MRC_SAMPLES_PCM16))
+        return fail(h, MRC_ERR_INVALID, "mrc_encode_chained: bad argument");
+    return chained_slabs(h, n_streams, pcm_left, pcm_right, sample_format, stream_stride, block_start, block_offset, block_a,
+                         block_b, reservoir_in, use_huffman, with_flush, num_samples, out_cap, stream_byte_offset,
+                         item_byte_offset, reservoir_out, reservoir_trace, total_bytes, stream, out,
+                         [](uint8_t*, int64_t, int64_t) { return (int)MRC_OK; });
+}
+
 int mrc_encode_chained_stream_pac(mrc_handle* h, int64_t n_streams, const void* pcm_left, const void* pcm_right,
                                   int sample_format, int64_t stream_stride, const int64_t* block_start,
                                   const int64_t* block_offset, const int32_t* block_a, const int32_t* block_b,
@@ -354,30 +491,29 @@ int mrc_encode_chained_stream_pac(mrc_handle* h, int64_t n_streams, const void* 
         return fail(h, MRC_ERR_INVALID, "mrc_encode_chained_stream_pac: bad argument");
     MRC_HIP(h, hipSetDevice(h->device));
     ChainBufs& C = h->chain;
-    const int64_t bound = mrc_chain_out_bound(h, n_streams, block_start, block_a, block_b, with_flush, num_samples != nullptr);
-    if (bound < 0) return fail(h, MRC_ERR_INVALID, "mrc_encode_chained_stream_pac: block shape out of range");
     const size_t pcmBytes = (size_t)n_streams * stream_stride * (sample_format == MRC_SAMPLES_PCM16 ? sizeof(int16_t) : sizeof(double));
     MRC_HIP(h, C.pcmL.reserve(pcmBytes ? pcmBytes : 1));
     MRC_HIP(h, C.pcmR.reserve(pcmBytes ? pcmBytes : 1));
-    MRC_HIP(h, C.out.reserve((size_t)bound + 1));
     SyncGuard guard{h->stream};
     if (pcmBytes) {
         MRC_HIP(h, hipMemcpyAsync(C.pcmL.p, pcm_left, pcmBytes, hipMemcpyHostToDevice, h->stream));
         MRC_HIP(h, hipMemcpyAsync(C.pcmR.p, pcm_right, pcmBytes, hipMemcpyHostToDevice, h->stream));
     }
-    // the device buffer holds the worst case; the caller's only has to hold what the streams really pack to
-    int rc = mrc_dev_encode_chained_pac(h, n_streams, C.pcmL.p, C.pcmR.p, sample_format, stream_stride, block_start,
-                                        block_offset, block_a, block_b, reservoir_in, use_huffman, with_flush, num_samples,
-                                        C.out.as<uint8_t>(), bound, stream_byte_offset, item_byte_offset, reservoir_out,
-                                        reservoir_trace, total_bytes, h->stream);
-    C.lastTotal = -1;
-    if (rc != MRC_OK) return rc;
-    C.lastTotal = *total_bytes;                          // (complete in C.out, whatever the caller's buffer holds)
-    if (*total_bytes > out_cap)
+    // every slab packs into the handle's device buffer (sized for the slab's worst case) and its bytes are copied behind the
+    // previous slab's in the caller's buffer, which only has to hold what the streams really pack to
+    hipStream_t st = h->stream;
+    mrc_handle* hh = h;
+    int rc = chained_slabs(h, n_streams, C.pcmL.p, C.pcmR.p, sample_format, stream_stride, block_start, block_offset, block_a,
+                           block_b, reservoir_in, use_huffman, with_flush, num_samples, out_cap, stream_byte_offset,
+                           item_byte_offset, reservoir_out, reservoir_trace, total_bytes, h->stream, nullptr,
+                           [out, st, hh](uint8_t* buf, int64_t n, int64_t at) {
+                               if (n) MRC_HIP(hh, hipMemcpyAsync(out + at, buf, (size_t)n, hipMemcpyDeviceToHost, st));
+                               MRC_HIP(hh, hipStreamSynchronize(st));      // (the next slab reuses the buffer)
+                               return (int)MRC_OK;
+                           });
+    if (rc == MRC_ERR_NOMEM)
         return fail(h, MRC_ERR_NOMEM, "mrc_encode_chained_stream_pac: out_cap too small (see total_bytes; mrc_chain_fetch_output)");
-    if (*total_bytes) MRC_HIP(h, hipMemcpyAsync(out, C.out.p, (size_t)*total_bytes, hipMemcpyDeviceToHost, h->stream));
-    MRC_HIP(h, hipStreamSynchronize(h->stream));
-    return MRC_OK;
+    return rc;
 }
 
 int mrc_chain_fetch_output(mrc_handle* h, uint8_t* out, int64_t out_cap, int64_t* total_bytes) {

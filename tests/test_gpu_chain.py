@@ -167,6 +167,46 @@ def test_many_streams_take_the_256_thread_scan(h):
         assert got[s] == alone[i], (s, i)
 
 
+@pytest.mark.parametrize("slab", [7, 64, 100000])
+def test_slabs_do_not_change_the_bytes(h, slab):
+    # MRC_OPT_CHAIN_SLAB_BLOCKS: a call is cut into slabs of at most `slab` blocks (whole streams while they fit, a longer
+    # stream alone in time slabs, the reservoir carried across) so that its device memory is bounded by the slab; bytes, stream
+    # and item offsets, reservoirs and the reservoir trace are those of the unslabbed call -- through the host-memory entry
+    # and the device-memory one
+    torch = pytest.importorskip("torch")
+    from mrcaudiocodec_amd import synth
+    from mrcaudiocodec_amd.batch import StreamEncoder
+    d = _long_switched()
+    hops = 11
+    x, sh_sw = synth.c4_transients(hops)
+    tone = synth.c1_sine(hops)
+    g = synth.c2_noise(hops, seed=3, sigma=0.05)
+    sh_long = [(i * 1024, 1024, 1024) for i in range(hops - 1)]
+    n = len(tone)
+    few = np.stack([np.stack([x + 0.3 * tone, 0.7 * x + 0.3 * tone + 0.05 * g])[:, :n], np.stack([tone, 0.9 * tone]),
+                    np.stack([0.5 * tone + g, 0.5 * tone - g]), np.stack([g, 0.2 * tone])])
+    few_shapes = [sh_sw, sh_long, sh_long[:6], sh_long[:3]]
+    cases = [(d["stream"][:, None, :], [d["shapes"]]), (np.ascontiguousarray(few.transpose(1, 0, 2)), few_shapes)]
+    for (st, shapes) in cases:
+        kw = dict(want_trace=True, want_items=True, num_samples=[sum(b for (_, _, b) in sh) for sh in shapes], reservoir_in=[5] * len(shapes))
+        h.set_option(6, 0)
+        want = h.encode_chained_pac(st[0], st[1], shapes, **kw)
+        h.set_option(6, slab)
+        try:
+            got = h.encode_chained_pac(st[0], st[1], shapes, **kw)
+            enc = StreamEncoder(handle=h)
+            dl, dr = (torch.from_numpy(np.ascontiguousarray(st[c])).cuda() for c in (0, 1))
+            dev = enc.encode_chained_pac(dl, dr, shapes, num_samples=kw["num_samples"], reservoir_in=kw["reservoir_in"], want_items=True)
+        finally:
+            h.set_option(6, 65536)
+        assert got["bytes"].tobytes() == want["bytes"].tobytes()
+        for k in ("stream_offset", "item_offset", "reservoir_out", "reservoir_trace"):
+            assert np.array_equal(got[k], want[k]), k
+        assert dev["bytes"].cpu().numpy().tobytes() == want["bytes"].tobytes()
+        assert np.array_equal(dev["stream_offset"], want["stream_offset"]) and np.array_equal(dev["item_offset"], want["item_offset"])
+        assert np.array_equal(dev["reservoir_out"], want["reservoir_out"])
+
+
 def test_output_beyond_the_first_buffer_is_fetched(h):
     # the binding's first buffer holds ~1 KB per block; at 12 bits per sample a block packs to more: the call reports the size
     # and the bytes -- complete in the handle's device buffer -- are fetched (mrc_chain_fetch_output), not encoded again
