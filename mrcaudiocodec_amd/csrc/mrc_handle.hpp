@@ -124,7 +124,7 @@ struct mrc_handle {
     bool exactSpread = false;        // mrc_set_option(MRC_OPT_EXACT_SPREAD)
     bool smrAllBands = false;        // mrc_set_option(MRC_OPT_SMR_ALL_BANDS)
     int chainThreads = 0;            // mrc_set_option(MRC_OPT_CHAIN_THREADS): workgroup size of the serial scan, 0 = by stream count
-    int64_t chainSlabBlocks = 65536; // mrc_set_option(MRC_OPT_CHAIN_SLAB_BLOCKS): blocks per slab of a chained encode (~3 GB of device memory)
+    int64_t chainSlabBlocks = 131072; // mrc_set_option(MRC_OPT_CHAIN_SLAB_BLOCKS): blocks per slab of a chained encode (~7.5 GB of device memory)
     bool chainForceFallback = false; // mrc_set_option(MRC_OPT_CHAIN_FORCE_REPAIR): tests of chain_prep_kernel's repair pass
     bool sensOn = false;             // mrc_set_option(MRC_OPT_SENSITIVITY): count decisions near a rounding edge ...
     mrc::DevBuf sens;                // ... here: MRC_SENS_COUNT counters (uint64), mrc_get_sensitivity

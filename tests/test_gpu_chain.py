@@ -198,7 +198,7 @@ def test_slabs_do_not_change_the_bytes(h, slab):
             dl, dr = (torch.from_numpy(np.ascontiguousarray(st[c])).cuda() for c in (0, 1))
             dev = enc.encode_chained_pac(dl, dr, shapes, num_samples=kw["num_samples"], reservoir_in=kw["reservoir_in"], want_items=True)
         finally:
-            h.set_option(6, 65536)
+            h.set_option(6, 131072)
         assert got["bytes"].tobytes() == want["bytes"].tobytes()
         for k in ("stream_offset", "item_offset", "reservoir_out", "reservoir_trace"):
             assert np.array_equal(got[k], want[k]), k

@@ -148,7 +148,7 @@ def test_full_size_joint_batch_properties():
 
 def test_long_single_stream_in_slabs_stays_under_4_GB():
     """ONE stereo stream of 2^18 hops through the chained call (the reference's whole encode loop, pacfileThem.py:1159-1214 +
-    Close()): cut into slabs of 65 536 blocks (MRC_OPT_CHAIN_SLAB_BLOCKS) it takes < 4 GB of device memory beside the PCM and
+    Close()): cut into slabs of 65 536 blocks (MRC_OPT_CHAIN_SLAB_BLOCKS; the default is 131 072) it takes < 4 GB of device memory beside the PCM and
     the output -- unslabbed it would hold ~45 KB per block, 12 GB -- and gives the bytes of the unslabbed call"""
     import numpy as np
     torch, bench, pacfile, enc, cfg = _env()
@@ -159,16 +159,18 @@ def test_long_single_stream_in_slabs_stays_under_4_GB():
     out = torch.empty((hops * 1100,), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize(dev)
     free0, _ = torch.cuda.mem_get_info(dev)
-    assert enc.h.get_option(6) == 65536
-    r = enc.encode_chained_pac(sl[None], sr[None], [shapes], num_samples=[hops * HOP], out=out)
-    torch.cuda.synchronize(dev)
-    free1, _ = torch.cuda.mem_get_info(dev)
-    assert free0 - free1 < 4e9, (free0 - free1) / 1e9
-    got = r["bytes"].clone()
-    enc.h.set_option(6, 0)
+    default = enc.h.get_option(6)
+    assert default == 131072
+    enc.h.set_option(6, 65536)
     try:
+        r = enc.encode_chained_pac(sl[None], sr[None], [shapes], num_samples=[hops * HOP], out=out)
+        torch.cuda.synchronize(dev)
+        free1, _ = torch.cuda.mem_get_info(dev)
+        assert free0 - free1 < 4e9, (free0 - free1) / 1e9
+        got = r["bytes"].clone()
+        enc.h.set_option(6, 0)
         whole = enc.encode_chained_pac(sl[None], sr[None], [shapes], num_samples=[hops * HOP], out=out)
     finally:
-        enc.h.set_option(6, 65536)
+        enc.h.set_option(6, default)
     assert int(r["total"]) == int(whole["total"]) and torch.equal(got, whole["bytes"])
     assert int(r["reservoir_out"][0]) == int(whole["reservoir_out"][0])
