@@ -45,13 +45,14 @@ def main():
     ap.add_argument("--varied", type=int, default=0, help="frames of the varied-level corpus (mono and as L/R pair)")
     ap.add_argument("--shapes", type=int, default=0, help="blocks per short / transition shape (mono, and a quarter joint)")
     ap.add_argument("--chunk", type=int, default=1024)
+    ap.add_argument("--seed-offset", type=int, default=0, help="added to every generator seed: a sweep over OTHER frames than the default's")
     args = ap.parse_args()
     h = Handle()
     t0 = time.time()
     for (a, b) in ((128, 128), (1024, 128), (128, 1024)) if args.shapes else ():
         for joint, n in ((False, args.shapes), (True, args.shapes // 4)):
             frames_bad, entries_bad, mdct_err = set(), 0, 0.0
-            rng = np.random.default_rng(a * 31 + b + int(joint))
+            rng = np.random.default_rng(a * 31 + b + int(joint) + args.seed_offset)
             for base in range(0, n, args.chunk * 4):
                 c = min(args.chunk * 4, n - base)
                 sig = 10.0 ** rng.uniform(-3.0, -0.3, (c, 1))          # per-block level, -60 .. -6 dBFS
@@ -82,10 +83,10 @@ def main():
         for base in range(0, n, args.chunk):
             c = min(args.chunk, n - base)
             res_in = rng.integers(-300, 800, c)
-            xl = varied_stream(c, 500000 + base)
+            xl = varied_stream(c, 500000 + args.seed_offset + base)
             bl = np.array(fast.blocks_from_stream(xl, 1024))
             if joint:
-                xr = 0.6 * xl + 0.4 * varied_stream(c, 900000 + base)
+                xr = 0.6 * xl + 0.4 * varied_stream(c, 900000 + args.seed_offset + base)
                 br = np.array(fast.blocks_from_stream(xr, 1024))
                 got = h.encode_joint(bl, br, 1024, 1024, res_in, want_mdct=True)
                 ref = fast.encode_joint_batch(bl, br, 1024, 1024, res_in)
@@ -108,7 +109,7 @@ def main():
         rng = np.random.default_rng(2026)
         for base in range(0, n, args.chunk):
             c = min(args.chunk, n - base)
-            seed = 100000 + base
+            seed = 100000 + args.seed_offset + base
             res_in = rng.integers(-300, 800, c)
             if joint:
                 s = synth.c3_stereo(c, seed_l=seed, seed_r=seed + 1)
