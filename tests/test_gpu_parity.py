@@ -171,6 +171,39 @@ def test_encode_joint_ms_long(h):
     assert np.abs(got["mdct"] - ref["mdct"]).max() <= MDCT_RTOL * np.abs(ref["mdct"]).max()
 
 
+def test_slope_nodes_and_their_fallback(h):
+    # smr_kernel's slope-node evaluation of the upper-side spreading sum (long and transition blocks) checks an error bound per
+    # line and sends a 64-line chunk back to the sorted sweep where it fails (lines that live on distant maskers); frames with
+    # too wide a slope range or too few maskers take the sorted sweep as a whole.  Content that mixes all of it (shares from
+    # tools/node_stats.py): loud noise (8 % of its frames outside the nodes' reach, 0.3 % of the others' chunks sent back),
+    # the varied-level corpus (most frames sorted sweep, 3 % of the node frames' chunks sent back), band-limited noise over a
+    # 16-bit floor and quiet noise (nodes everywhere), three tones (13 maskers: sorted sweep).  Thresholds / SMRs within 1e-9 dB
+    # of the oracle's, then every integer of the encode -- per corpus through the few-block path and all together through the
+    # batch kernels.
+    from mrcaudiocodec_amd import synth
+    rng = np.random.default_rng(12)
+    n = 48
+    g = rng.normal(0, 1, (n + 1) * 1024)
+    G = np.fft.rfft(g)
+    G[int(len(G) * 9000 / 24000):] = 0
+    g = np.fft.irfft(G, len(g))
+    lp = synth.pcm_to_float(np.clip(np.rint(g / g.std() * 0.05 * 32767), -32767, 32767))
+    lp[:1024] = 0
+    tones = synth.c1_sine(n) + 0.2 * synth.c1_sine(n, freq=5210.0) + 0.05 * synth.c1_sine(n, freq=11000.0)
+    streams = [synth.c2_noise(n, seed=77, sigma=0.3), synth.c6_varied(n, seed=21), lp, synth.c2_noise(n, seed=78, sigma=0.002), tones]
+    corpora = [np.array(fast.blocks_from_stream(x, 1024, n)) for x in streams]
+    sfb = fast.bands_for(1024, 1024)
+    for blocks in corpora:
+        smr, thr = h.smr(blocks, 1024, 1024, want_thresh=True)
+        X = fast.mdct_batch(blocks, 1024, 1024)
+        s, Xs = fast.overall_scale_batch(X, 4)
+        assert np.abs(thr - fast.masked_threshold_batch(blocks, 1024, 48000)).max() <= DB_ATOL
+        assert np.abs(smr - fast.smr_batch(blocks, Xs, s, 48000, sfb)).max() <= DB_ATOL
+        _assert_int_parity(h.encode_mono(blocks, 1024, 1024), fast.encode_mono_batch(blocks, 1024, 1024))
+    big = np.concatenate(corpora)                                    # (> 64 blocks per call: the batch kernels)
+    _assert_int_parity(h.encode_mono(big, 1024, 1024), fast.encode_mono_batch(big, 1024, 1024))
+
+
 def test_spread_modes_agree(h):
     # MRC_OPT_EXACT_SPREAD: the reference's own per-(masker, line) expression with pow() vs the default
     # factored form I_m * 2^(slope*u).  Same integers; thresholds within 1e-10 dB of each other.
