@@ -467,7 +467,11 @@ class Handle:
                                                    buf.size, *tail)
             if rc == MRC_ERR_NOMEM and 0 < int(total[0]) <= bound:
                 buf = np.empty(int(total[0]), np.uint8)
-                self._check(lib.mrc_chain_fetch_output(self._h, vp(buf), buf.size, total.ctypes.data_as(_i64p)))
+                if lib.mrc_chain_fetch_output(self._h, vp(buf), buf.size, total.ctypes.data_as(_i64p)) != 0:
+                    # a call of several slabs keeps only its last slab on the device: encode again into a buffer of the
+                    # size the first pass reported
+                    self._check(lib.mrc_encode_chained_stream_pac(self._h, n_streams, vp(pl), vp(pr), fmt, stride, *sched,
+                                                                  vp(buf), buf.size, *tail))
             else:
                 self._check(rc)
             buf = buf[:int(total[0])]

@@ -528,6 +528,9 @@ __device__ unsigned long long gNodeStats[4];     // units with nodes, units with
 #ifndef MRC_PROFILE_SKIP                         // profiling aid (wrong results): bit mask of sweep parts to leave out,
 #define MRC_PROFILE_SKIP 0                       // 1 far field, 2 direct pairs, 4 partial pairs, 8 chunk tail
 #endif
+#ifndef MRC_PROFILE_NODESKIP                     // profiling aid (wrong results): 1 no node terms / row scan, 2 no remainder pairs
+#define MRC_PROFILE_NODESKIP 0                   // (any value also switches the error-bound fallback off)
+#endif
 #ifndef MRC_DIRECT_UNROLL                        // pairs in flight per lane in the direct loops
 #define MRC_DIRECT_UNROLL 4
 #endif
@@ -1212,9 +1215,6 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 if (live && i < L && r <= nR) nodeQ[r * kNodeCols + col] = v[i] + off;
             }
         };
-#ifndef MRC_PROFILE_NODESKIP                     // profiling aid (wrong results): 1 no node terms, 2 no remainder pairs, 4 no Horner
-#define MRC_PROFILE_NODESKIP 0
-#endif
         bool scansDone = false;
         if constexpr (kNodes) {
             if (useNodes) {                              // (workgroup-uniform)

@@ -217,6 +217,8 @@ def test_output_beyond_the_first_buffer_is_fetched(h):
         got = ppac.encode_stereo_stream(hd, stream, shapes)
         assert len(got) > len(shapes) * 1024 + 2 * 4096
         assert got == ppac.encode_stereo_stream_per_block(hd, stream, shapes)
+        hd.set_option(6, 5)                                            # several slabs: nothing to fetch, the binding encodes again
+        assert ppac.encode_stereo_stream(hd, stream, shapes) == got
     finally:
         hd.close()
 
