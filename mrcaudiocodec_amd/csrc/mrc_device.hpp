@@ -17,16 +17,14 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
 
 // 16-bit PCM code -> signed fraction exactly as the reference's file reader does (pcmfile.py:91-100 through
 // quantize.py:90-111): x = (2 c) / 65535 with ONE rounding (IEEE division), and -32768 -> +0.0 (its magnitude 2^15 is
-// read as a bare sign bit).  The division is replaced by its reciprocal-and-correct form -- q0 = n r,
-// q = fma(fma(-q0, 65535, n), r, q0), r = fl(1/65535) -- which gives the correctly rounded quotient for every one of
-// the 65535 codes (checked exhaustively in exact arithmetic: tests/test_abi.py::test_pcm16_map_is_exact; on the device
-// against the reference's own values: tests/test_gpu_pcm16.py).
+// read as a bare sign bit).  2 / 65535 = 2^-15 (1 + 2^-16 + 2^-32 + ...) repeats every 16 bits, so its double-double
+// form is the same mantissa twice, 64 binades apart, and q = fma(c, kHi, c kLo) is the correctly rounded quotient for
+// every one of the 65535 codes (checked exhaustively in exact arithmetic: tests/test_abi.py::test_pcm16_map_is_exact;
+// on the device against the reference's own values: tests/test_gpu_pcm16.py).  Conversion, product, fma: three
+// instructions per sample where the reciprocal-and-correct form of rounds 1-3 took five.
 __device__ __forceinline__ double pcm16_to_frac(int c) {
-    const double n = (double)(2 * c);
-    const double r = 0x1.0001000100010p-16;
-    const double q0 = n * r;
-    const double q = fma(fma(-q0, 65535.0, n), r, q0);
-    return c == -32768 ? 0.0 : q;
+    const double n = (double)(c == -32768 ? 0 : c);
+    return fma(n, 0x1.0001000100010p-15, n * 0x1.0001000100010p-79);
 }
 // one sample of a channel held as float64 signed fractions or as int16 PCM codes
 __device__ __forceinline__ double sample_of(const double* __restrict__ p, int64_t i) { return p[i]; }
@@ -103,6 +101,20 @@ __device__ __forceinline__ double wave_allreduce(double v, Op op) {
 }
 __device__ __forceinline__ double wave_max(double v) {
     return wave_allreduce(v, [](double a, double b) { return fmax(a, b); });
+}
+// v_max_f64 as it is: fmax() makes the compiler canonicalise operands that come out of a lane exchange (a second
+// v_max_f64 x, x per operand, against signalling NaNs); the values reduced with this are ratios and magnitudes
+__device__ __forceinline__ double max_raw(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// maximum over each 16-lane row, in every lane of the row
+__device__ __forceinline__ double row_max(double v) {
+    v = max_raw(v, dpp_move<0xB1>(v));
+    v = max_raw(v, dpp_move<0x4E>(v));
+    v = max_raw(v, dpp_move<0x141>(v));
+    return max_raw(v, dpp_move<0x128>(v));
 }
 __device__ __forceinline__ double wave_sum(double v) {
     return wave_allreduce(v, [](double a, double b) { return a + b; });
@@ -287,6 +299,53 @@ __device__ __forceinline__ double2* fft_lds_1024(double2* A, double2* B, const d
     fft_pass<4, true, TwQuarter, NT>(B, A, 1024, 64, W, tid);
     __syncthreads();
     fft_pass<4, true, TwQuarter, NT>(A, B, 1024, 256, W, tid);
+    __syncthreads();
+    return B;
+}
+// The long block's transform for a thread that already HOLDS the four inputs of its first butterfly (smr_kernel: the windowed
+// samples it has just loaded) -- the first pass runs on registers, no trip through the first buffer -- and with the twiddles of
+// the other four passes read from a per-pass table in global memory (DevShape::fftTw: for pass p the three factors of
+// butterfly k = tid mod p side by side, 48 bytes per lane, requested a pass ahead).  The LDS quadrant cost a gather per factor
+// at strides of 64 r, 16 r, 4 r entries -- up to sixteen lanes on one bank -- plus the index and quadrant fix-up arithmetic.
+// Same values (the table is built from the quadrant with the same fix-ups), same operations, same order as fft_lds_1024.
+struct Tw3 { double2 w[3]; };
+__device__ __forceinline__ Tw3 fft1024_twiddles(const double2* __restrict__ tw, int pass /* 1..4 */, int tid) {
+    // passes p = 4, 16, 64, 256: tables of 3 p entries behind each other
+    const int p = 1 << (2 * pass), base = 3 * ((p - 4) / 3);              // 3 (4 + 16 + ... ) entries before this pass
+    const double2* src = tw + base + 3 * (tid & (p - 1));
+    return Tw3{{src[0], src[1], src[2]}};
+}
+template <int P>
+__device__ __forceinline__ void fft1024_pass(const double2* __restrict__ in, double2* __restrict__ out, const Tw3& W, int tid) {
+    constexpr int lp = P == 4 ? 2 : P == 16 ? 4 : P == 64 ? 6 : 8;
+    const int k = tid & (P - 1);
+    const int j = (tid >> lp) * (P * 4) + k;
+    double2 u[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) u[r] = in[tid + r * 256];
+#pragma unroll
+    for (int r = 1; r < 4; ++r) u[r] = cmul(u[r], W.w[r - 1]);
+    butterfly<4>(u);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[j + q * P] = u[q];
+}
+// u: in[tid + r 256], r = 0..3; 256 threads.  Returns the buffer with the natural-order result (A).
+__device__ __forceinline__ double2* fft_regs_1024(double2 (&u)[4], double2* A, double2* B, const double2* __restrict__ tw,
+                                                  Tw3 w1, int tid) {
+    butterfly<4>(u);                                     // pass p = 1: unit twiddles
+#pragma unroll
+    for (int q = 0; q < 4; ++q) B[4 * tid + q] = u[q];
+    Tw3 w2 = fft1024_twiddles(tw, 2, tid);
+    __syncthreads();
+    fft1024_pass<4>(B, A, w1, tid);
+    Tw3 w3 = fft1024_twiddles(tw, 3, tid);
+    __syncthreads();
+    fft1024_pass<16>(A, B, w2, tid);
+    Tw3 w4 = fft1024_twiddles(tw, 4, tid);
+    __syncthreads();
+    fft1024_pass<64>(B, A, w3, tid);
+    __syncthreads();
+    fft1024_pass<256>(A, B, w4, tid);
     __syncthreads();
     return B;
 }

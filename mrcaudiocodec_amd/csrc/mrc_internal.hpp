@@ -17,6 +17,8 @@ constexpr int kMaxBands = MRC_MAX_BANDS;
 
 // Everything a kernel needs to know about one block shape (a,b).  POD, passed by value; the
 // pointers address one device blob owned by the handle.
+struct LineConstants { double z, quiet, lowE; int band, pad; };      // 32 bytes: two 16-byte loads per line
+
 struct DevShape {
     int a, b, N, halfN, Q, H;        // N = a+b, halfN = N/2 lines, Q = N/4 (MDCT FFT), H = N/2 (psycho FFT)
     int shift;                       // (b-a)/4: signed circular shift that maps n0=(b+1)/2 to the standard phase
@@ -38,12 +40,14 @@ struct DevShape {
     const double2* wQ;               // [Q] exp(-2 pi i t/Q)
     const double2* wH;               // [H] exp(-2 pi i t/H)
     const double2* wN;               // [H] exp(-2 pi i k/N)
+    const double2* fftTw;            // H = 1024 only: per-pass twiddles of the psycho FFT (dev::fft_regs_1024), else null
     const double* zb;                // [halfN] Bark(MDCTFreq) (psychoac.py:27-29,142-143)
     const double* quiet;             // [halfN] Intensity(Thresh(MDCTFreq)) (psychoac.py:155)
     const double* lowE;              // [halfN] 2^(2.7 log2(10) (zb+1/2)): per-line factor of the -27 dB/Bark lower slope
     const int* bandLo;               // [nBands]
     const int* bandN;                // [nBands]
     const unsigned char* bandOfLine; // [halfN]
+    const struct LineConstants* lineC;  // [halfN] zb, quiet, lowE and the band of a line side by side (smr_kernel's sweep)
     const unsigned short* loLine;    // [halfN] first line j with zb[j] - zb[k] >= -1/2 (search hint)
     const unsigned short* hiLine;    // [halfN] first line j with zb[j] - zb[k] > 1/2, halfN if none (search hint)
     double linesPerHz;               // N / sampleRate

@@ -26,6 +26,7 @@
 #include "mrc_device.hpp"
 
 #include <algorithm>
+#include <type_traits>
 #include "mrc_log10.hpp"
 
 namespace mrc {
@@ -796,6 +797,11 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     // (even, odd) sample pairs come as ONE load each when the block starts at an even sample of an aligned channel
     const bool pairAligned = !(off & 1) && !(reinterpret_cast<uintptr_t>(chL) & (2 * sizeof(SampleT) - 1)) &&
                              (!chR || !(reinterpret_cast<uintptr_t>(chR) & (2 * sizeof(SampleT) - 1)));
+    // long blocks: a thread's four samples are the inputs of its first butterfly and stay in registers (fft_regs_1024)
+    constexpr bool kFftRegs = LONG && NT == 256 && kPre == 4;
+    [[maybe_unused]] double2 fftIn[4];
+    [[maybe_unused]] Tw3 fftW1;
+    if constexpr (kFftRegs) fftW1 = fft1024_twiddles(S.fftTw, 1, tid);
     for (int n0 = tid; n0 < H; n0 += NT * kPre) {
         double e[kPre], o[kPre], he[kPre], ho[kPre];
 #pragma unroll
@@ -810,7 +816,8 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
 #pragma unroll
         for (int u = 0; u < kPre; ++u) {
             const int n = n0 + u * NT;
-            if (n < H) A[n] = make_double2(e[u] * he[u], o[u] * ho[u]);
+            if constexpr (kFftRegs) fftIn[u] = make_double2(e[u] * he[u], o[u] * ho[u]);
+            else if (n < H) A[n] = make_double2(e[u] * he[u], o[u] * ho[u]);
         }
     }
     const double xiInv = 1.0 / S.xiDen;
@@ -831,7 +838,10 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         if (TAB != kExpTab) e2Pre64 = kExp2Tab[tid & (kExpTab - 1)];
     }
     double2* T;
-    if (lay.twOff >= 0) {
+    if constexpr (kFftRegs) {
+        MRC_PHASE(0); MRC_STOP(0);
+        T = fft_regs_1024(fftIn, A, B, S.fftTw, fftW1, tid);
+    } else if (lay.twOff >= 0) {
         double2* Wq = reinterpret_cast<double2*>(smem + lay.twOff);
         for (int t = tid; t < H / 4; t += NT) Wq[t] = S.wH[t];
         __syncthreads();
@@ -1222,9 +1232,9 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 // other scans on the other waves
                 if (!(MRC_PROFILE_NODESKIP & 1)) node_terms();
                 __syncthreads();
-                if (waveU == 0) { if (!(MRC_PROFILE_NODESKIP & 1)) node_scan(); }
-                else if (waveU == 1) scan_pi();
-                else if (waveU == 2) { scan_counts(cntArr); scan_sc(); }
+                if (waveU == 1) { if (!(MRC_PROFILE_NODESKIP & 1)) node_scan(); }      // (not the wave of the maskers beyond the first NT)
+                else if (waveU == 2) scan_pi();
+                else if (waveU == 3) { scan_counts(cntArr); scan_sc(); }
                 else scan_counts(nUpArr);
                 scansDone = true;
             }
@@ -1252,8 +1262,13 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         struct LineConst { double z, quiet, lowE, x; int bnd; };
         auto chunk_of = [&](int i) { return i * nWaves + ((i & 1) ? (nWaves - 1 - waveU) : waveU); };
         auto load_consts = [&](int i) {
-            const int kc = min(chunk_of(i) * kWave + lane, M - 1);
-            return LineConst{S.zb[kc], S.quiet[kc], S.lowE[kc], X[kc], S.bandOfLine[kc]};
+            // (byte offsets as 32-bit unsigned values: scalar base + vector offset addressing, no 64-bit address arithmetic)
+            const unsigned kc = (unsigned)min(chunk_of(i) * kWave + lane, M - 1);
+            const char* lc = reinterpret_cast<const char*>(S.lineC) + kc * (unsigned)sizeof(LineConstants);
+            const double2 a = *reinterpret_cast<const double2*>(lc);
+            const double2 b = *reinterpret_cast<const double2*>(lc + 16);
+            const double x = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(X) + kc * 8u);
+            return LineConst{a.x, a.y, b.x, x, __double2loint(b.y)};
         };
         // in-band maskers [from, cnt) and the lower side on top of `tot` (quiet threshold + upper side): the line's masked intensity
         auto tail_sum = [&](double tot, int cnt, int from, double lowE) {
@@ -1274,10 +1289,16 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         // instead of two log10 per line (the difference to the reference's order of roundings is ~1e-14 dB, five
         // orders below what the FFT in front of it already differs by).  Lines on the floor, and every line when
         // the caller wants the thresholds themselves, take the reference's formula.
-        auto finish = [&](const LineConst& cur, int k, double t) {
+        // (a2 of a line: the intensity of its own MDCT line, psychoac.py:212)
+        auto line_a2 = [&](const LineConst& cur) {
             const double xs = ldexp(cur.x, scale);                           // codecThem.py:323 (exact)
-            const double a2 = 2. * (xs * xs) / (1. / 2.);
-            const bool plain = thresh != nullptr || !(a2 >= kSplFloorGuard && t >= kSplFloorGuard);
+            return 2. * (xs * xs) / (1. / 2.);
+        };
+        auto line_plain = [&](double a2, double t) { return thresh != nullptr || !(a2 >= kSplFloorGuard && t >= kSplFloorGuard); };
+        // noPlain: the caller has checked that no lane of the chunk takes the reference's formula (no call in its loop)
+        auto finish = [&](const LineConst& cur, int k, double t, auto noPlain) {
+            const double a2 = line_a2(cur);
+            const bool plain = decltype(noPlain)::value ? false : line_plain(a2, t);
             double ex = -1e300, q = 0.0;
             if (plain) {
                 double thr;
@@ -1288,15 +1309,18 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
             }
             const int bnd = cur.bnd;                     // lanes past the end repeat the last line: maxima unchanged
             if (__all(bnd == __builtin_amdgcn_readfirstlane(bnd))) {
-                const double qBest = wave_max(q);        // whole chunk inside one band (the wide top bands)
-                if (lane == 0) atomicMax(&ratioKey[bnd], (unsigned long long)__double_as_longlong(qBest));
+                // whole chunk inside one band (the wide top bands): 64 lanes on one LDS address would be served one by
+                // one; the maximum of each 16-lane row is taken in registers and four lanes go to the LDS
+                const bool rowHead = (lane & 15) == 0;
+                const double qBest = row_max(q);
+                if (rowHead) atomicMax(&ratioKey[bnd], (unsigned long long)__double_as_longlong(qBest));
                 if (__any(plain)) {
-                    const double best = wave_max(ex);
-                    if (lane == 0) atomicMax(&bandKey[bnd], order_key(best));
+                    const double best = row_max(ex);
+                    if (rowHead) atomicMax(&bandKey[bnd], order_key(best));
                 }
                 if (wantPeak) {
-                    const double pk = wave_max(fabs(cur.x));
-                    if (lane == 0) atomicMax(&peakKey[bnd], (unsigned long long)__double_as_longlong(pk));
+                    const double pk = row_max(fabs(cur.x));
+                    if (rowHead) atomicMax(&peakKey[bnd], (unsigned long long)__double_as_longlong(pk));
                 }
             } else {
                 atomicMax(&ratioKey[bnd], (unsigned long long)__double_as_longlong(q));
@@ -1323,17 +1347,14 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
             double ps = xr * xr;
             ps *= ps; ps *= ps; ps *= ps;                // (h R / |sigma_0|)^16
             const double psiStar = ps * kExpMinus16;
-            LineConst nxt = load_consts(0);
-            for (int i = 0; sweepOn && chunk_of(i) < nChunks; ++i) {
-                const int c = chunk_of(i);
-                const int k = c * kWave + lane;
-                const int kc = min(k, M - 1);
-                const LineConst cur = nxt;
-                nxt = load_consts(i + 1);
-                if (haveSwitch && !__any(needBand[cur.bnd])) continue;                           // (see needBand)
+            // The chunks where the evaluation below is not the last word -- a line whose error bound fails, a line on the
+            // SPL floor, every chunk when the caller wants the thresholds -- are set aside (a bit per chunk of the wave) and
+            // done after the loop: the out-of-line calls they need would otherwise sit in the hot loop and cost it the
+            // scalar registers a call clobbers (its pointers and masks were being reloaded from a spill lane every chunk).
+            struct NodeEval { double t, bound; int cnt, nUp; };
+            auto node_chunk = [&](const LineConst& cur, int kc) {
                 const int cnt = cntArr[kc], nUp = nUpArr[kc];      // maskers that reach the line / lie > 1/2 Bark below it
                 const double zq = cur.z - 0.5;
-                MRC_PHASE(6);
                 const int q = nUp >> 2, rem = nUp & 3;   // (kNodeC = 4)
                 const double* row = nodeQ + q * kNodeCols;
                 const double E0 = exp2_tab64<TAB>(nodeS0, zq, e2tab);
@@ -1341,19 +1362,42 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 const double errBound = fma(psiStar, row[kNodeR], (kNodeRoundEps * E0) * row[kNodeR + 1]);
                 const double up = (MRC_PROFILE_NODESKIP & 2) ? node_line<0, TAB>(row, mt, e2tab, 4 * q, rem, nPeaks - 1, zq, E0, g)
                                                              : node_line<kNodeC - 1, TAB>(row, mt, e2tab, 4 * q, rem, nPeaks - 1, zq, E0, g);
+                return NodeEval{tail_sum(cur.quiet + up, cnt, nUp, cur.lowE), errBound, cnt, nUp};
+            };
+            unsigned setAside = 0;                       // (wave-uniform)
+            LineConst nxt = load_consts(0);
+            for (int i = 0; sweepOn && chunk_of(i) < nChunks; ++i) {
+                const int k = chunk_of(i) * kWave + lane;
+                const LineConst cur = nxt;
+                nxt = load_consts(i + 1);
+                if (haveSwitch && !__any(needBand[cur.bnd])) continue;                           // (see needBand)
+                MRC_PHASE(6);
+                const NodeEval ev = node_chunk(cur, min(k, M - 1));
                 MRC_PHASE(8);
-                double t = tail_sum(cur.quiet + up, cnt, nUp, cur.lowE);
-                if (!MRC_PROFILE_NODESKIP && __any(!(errBound <= kNodeTol * t))) {
+                const bool odd = (!MRC_PROFILE_NODESKIP && !(ev.bound <= kNodeTol * ev.t)) || line_plain(line_a2(cur), ev.t);
+                if (__any(odd)) { setAside |= 1u << i; continue; }
+                MRC_NODE_COUNT(2);
+                finish(cur, k, ev.t, std::true_type{});
+                MRC_PHASE(10);
+            }
+            while (setAside) {
+                const int i = __builtin_ctz(setAside);
+                setAside &= setAside - 1;
+                const int c = chunk_of(i);
+                const int k = c * kWave + lane;
+                const LineConst cur = load_consts(i);
+                const NodeEval ev = node_chunk(cur, min(k, M - 1));
+                double t = ev.t;
+                if (!MRC_PROFILE_NODESKIP && __any(!(ev.bound <= kNodeTol * ev.t))) {
                     // a line of this chunk lives on what the interpolation does worst: the chunk goes back to the sorted sweep
                     MRC_NODE_COUNT(3);
                     if (sens && lane == 0) atomicAdd(&sens[4], 1ull);
-                    const double tot = cur.quiet + upper_cold<TAB>(mt, e2tab, S.zb, M, c, lane, nUp, cnt, cur.z, slMid, spreadHalf);
-                    t = tail_sum(tot, cnt, __builtin_amdgcn_readlane(nUp, kWave - 1), cur.lowE);
+                    const double tot = cur.quiet + upper_cold<TAB>(mt, e2tab, S.zb, M, c, lane, ev.nUp, ev.cnt, cur.z, slMid, spreadHalf);
+                    t = tail_sum(tot, ev.cnt, __builtin_amdgcn_readlane(ev.nUp, kWave - 1), cur.lowE);
                 } else {
                     MRC_NODE_COUNT(2);
                 }
-                finish(cur, k, t);
-                MRC_PHASE(10);
+                finish(cur, k, t, std::false_type{});
             }
             }
         } else {
@@ -1406,7 +1450,7 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 continue;
             }
             // no line of the chunk is above the band of the maskers from max nUp on: a line that sees one is inside +-1/2 Bark
-            finish(cur, k, tail_sum(tot, cnt, __builtin_amdgcn_readlane(nUp, kWave - 1), cur.lowE));
+            finish(cur, k, tail_sum(tot, cnt, __builtin_amdgcn_readlane(nUp, kWave - 1), cur.lowE), std::false_type{});
             MRC_PHASE(10);
         }
         }

@@ -266,11 +266,31 @@ bool build_shape(const mrc_config& cfg, int a, int b, HostShape* out, std::strin
     ms_plan(out->bandLo, out->bandN, &msPlanV, &S.msLeaves, &S.msInternal);
     if (S.msLeaves + S.msInternal > 64) { *err = "band table too fine for the M/S summation plan"; return false; }
 
+    // per-pass twiddles of the 1024-point psycho FFT: for the passes p = 4, 16, 64, 256 and k < p the factors
+    // w^(k r 1024 / (4 p)), r = 1..3, taken from the FIRST QUADRANT of wH with the fix-ups w(s + q n/4) = w(s) (-i)^q -- the
+    // values dev::TwQuarter hands out (fft_lds_1024), so that both transforms agree bit for bit
+    std::vector<double2> fftTw;
+    if (S.H == 1024) {
+        for (int p = 4; p <= 256; p *= 4)
+            for (int k = 0; k < p; ++k)
+                for (int r = 1; r <= 3; ++r) {
+                    const int t = k * r * (1024 / (4 * p));
+                    const double2 v = wH[t & 255];
+                    const int q = t >> 8;
+                    double2 o = (q & 1) ? make_double2(v.y, -v.x) : v;
+                    if (q & 2) o = make_double2(-o.x, -o.y);
+                    fftTw.push_back(o);
+                }
+    }
+    std::vector<LineConstants> lineC(S.halfN);
+    for (int k = 0; k < S.halfN; ++k) lineC[k] = LineConstants{zb[k], quiet[k], lowE[k], (int)bandOfLine[k], 0};
+
     BlobWriter bw;
     size_t oWin = bw.put(win), oHann = bw.put(hann), oPre = bw.put(pre), oPost = bw.put(post);
     size_t oWQ = bw.put(wQ), oWH = bw.put(wH), oWN = bw.put(wN), oZb = bw.put(zb), oQuiet = bw.put(quiet), oLowE = bw.put(lowE);
     size_t oLo = bw.put(out->bandLo), oCnt = bw.put(out->bandN), oBol = bw.put(bandOfLine);
     size_t oLoLine = bw.put(loLine), oHiLine = bw.put(hiLine), oMsPlan = bw.put(msPlanV);
+    size_t oLineC = bw.put(lineC), oFftTw = bw.put(fftTw);
     void* blob = nullptr;
     if (hipMalloc(&blob, bw.bytes.size()) != hipSuccess) { *err = "hipMalloc(shape tables) failed"; return false; }
     if (hipMemcpy(blob, bw.bytes.data(), bw.bytes.size(), hipMemcpyHostToDevice) != hipSuccess) {
@@ -290,6 +310,8 @@ bool build_shape(const mrc_config& cfg, int a, int b, HostShape* out, std::strin
     S.loLine = (const unsigned short*)(base + oLoLine);
     S.hiLine = (const unsigned short*)(base + oHiLine);
     S.msPlan = (const int*)(base + oMsPlan);
+    S.lineC = (const LineConstants*)(base + oLineC);
+    S.fftTw = fftTw.empty() ? nullptr : (const double2*)(base + oFftTw);
     out->blob = blob;
     return true;
 }

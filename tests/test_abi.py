@@ -106,20 +106,17 @@ def test_table_log10_accuracy(tmp_path):
 
 def test_pcm16_map_is_exact():
     """dev::pcm16_to_frac (csrc/mrc_device.hpp) replaces the reference's IEEE division 2c/65535 (pcmfile.py:91-100 via
-    quantize.py:90-111) by q0 = n r, q = fma(fma(-q0, 65535, n), r, q0) with r = fl(1/65535).  Checked here for EVERY
-    16-bit code in exact rational arithmetic (each device operation rounds once: Fraction -> float is that rounding),
-    against the values the reference's own function returned for the recorded codes."""
+    quantize.py:90-111) by q = fma(c, kHi, c kLo) with kHi + kLo = 2/65535 to 106 bits.  Checked here for EVERY 16-bit code
+    in exact rational arithmetic (each device operation rounds once: Fraction -> float is that rounding), against the
+    values the reference's own function returned for the recorded codes."""
     from fractions import Fraction
-    r = float.fromhex("0x1.0001000100010p-16")
-    assert r == float(Fraction(1, 65535))
+    k_hi, k_lo = float.fromhex("0x1.0001000100010p-15"), float.fromhex("0x1.0001000100010p-79")
+    assert k_hi == float(Fraction(2, 65535)) and k_lo == float(Fraction(2, 65535) - Fraction(k_hi))
 
     def dev_map(c):
-        if c == -32768:
-            return 0.0
-        n = float(2 * c)
-        q0 = float(Fraction(n) * Fraction(r))
-        rem = float(Fraction(n) - Fraction(q0) * 65535)
-        return float(Fraction(q0) + Fraction(rem) * Fraction(r))
+        n = 0 if c == -32768 else c
+        low = float(Fraction(n) * Fraction(k_lo))
+        return float(Fraction(n) * Fraction(k_hi) + Fraction(low))
     for c in range(-32768, 32768):
         want = 0.0 if c == -32768 else (2.0 * c) / 65535.0
         assert dev_map(c) == want, c
