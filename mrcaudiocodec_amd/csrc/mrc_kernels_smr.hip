@@ -658,13 +658,15 @@ __device__ __attribute__((noinline)) double upper_cold(const double* mt, const d
 
 
 #ifdef MRC_PROFILE_PHASES
-// profiling build only (make EXTRA=-DMRC_PROFILE_PHASES): shader-clock cycles per kernel phase, summed over waves
+// profiling build only (make EXTRA=-DMRC_PROFILE_PHASES): shader-clock cycles per kernel phase, summed over the waves of
+// every 64th workgroup (per workgroup in LDS, flushed once at its end: an atomic to global memory per marker from every wave
+// made the build sixteen times slower than the kernel it was meant to describe)
 __device__ unsigned long long gPhaseCycles[16];
 #define MRC_PHASE(i)                                                                  \
     do {                                                                              \
-        const long long now_ = clock64();                                             \
-        if (lane == 0) atomicAdd(&gPhaseCycles[i], (unsigned long long)(now_ - tPhase_)); \
-        tPhase_ = clock64();                                                          \
+        const long long now_ = __builtin_readcyclecounter();                          \
+        if (lane == 0) atomicAdd(&sPhase_[i], (unsigned long long)(now_ - tPhase_));  \
+        tPhase_ = __builtin_readcyclecounter();                                       \
     } while (0)
 #else
 #define MRC_PHASE(i) do { } while (0)
@@ -767,7 +769,10 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     double* piLo = piHi + (last / 2 + 2);                //   the masker intensities, double-double (hi, lo)
 
 #ifdef MRC_PROFILE_PHASES
-    long long tPhase_ = clock64();
+    __shared__ unsigned long long sPhase_[16];
+    if (threadIdx.x < 16) sPhase_[threadIdx.x] = 0ull;
+    __syncthreads();
+    long long tPhase_ = __builtin_readcyclecounter();
 #endif
     // The phases before the sweep are chains of short instruction bursts between barriers and memory waits; the sweep
     // is one long stream of VALU work.  Waves of the four workgroups that share a SIMD are in different phases: the
@@ -1016,8 +1021,9 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
             atomicMax(&slopeKey[1], order_key(slHi));
         }
     }
+    MRC_PHASE(4);
     __syncthreads();
-    MRC_PHASE(4); MRC_STOP(4);
+    MRC_PHASE(12); MRC_STOP(4);
 
     // psychoac.py:214-217: SMR of a band = max over its lines of (SPL of the line - masked threshold),
     // accumulated with LDS integer max-atomics on an order-preserving key (initialised by the table
@@ -1090,10 +1096,15 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         double* piH = piHi;
         double* piL = piLo;
         if (kNodes && useNodes) { piH = mt + 4 * nPeaks; piL = piH + (nPeaks + 1); }
-        auto scan_sc = [&]() {
-            // kWave * kSeg >= the block's maximum number of peaks + 1: 512 >= N/4 in general; a block of DIM lines has at
-            // most (DIM - 101) / 2 (13 for the short block: one per lane; 237 for the transition blocks: four)
-            constexpr int kSeg = DIM == 128 ? 1 : DIM == 576 ? 4 : 8;
+        // kWave * kSeg >= the block's maximum number of peaks + 1: 512 >= N/4 in general; a block of DIM lines has at
+        // most (DIM - 101) / 2 (13 for the short block: one per lane; 237 for the transition blocks: four; 461 for the long
+        // block: eight -- but a frame that takes the slope nodes has at most 308: five.  Besides the shorter serial chain,
+        // five entries of 32 bytes per lane put the lanes 160 bytes apart; at 256 bytes all 64 read the same bank)
+        constexpr int kSegAny = DIM == 128 ? 1 : DIM == 576 ? 4 : 8;
+        constexpr int kSegNodes = DIM == 1024 ? 5 : kSegAny;
+        static_assert(DIM != 1024 || kWave * kSegNodes > node_max_maskers(1024), "segments of the scans");
+        auto scan_sc = [&](auto segC) {
+            constexpr int kSeg = decltype(segC)::value;
             double loc[kSeg];
             double run = 0.0;
             const int seg = kWave - 1 - lane;           // lanes take the segments in REVERSE order, so that the suffix
@@ -1112,11 +1123,11 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
             }
             if (lane == 0) sc[nPeaks] = 0.0;
         };
-        auto scan_pi = [&]() {
+        auto scan_pi = [&](auto segC) {
             // pi[m] = I_0 + ... + I_{m-1} in double-double: the in-band sum of a line is a DIFFERENCE of two
             // prefix sums, and with ~106 bits the difference is exact to far below one ulp of the result even
             // when a loud masker sits in the prefix (dynamic range of I within a frame < 2^50)
-            constexpr int kSeg = DIM == 128 ? 1 : DIM == 576 ? 4 : 8;
+            constexpr int kSeg = decltype(segC)::value;
             double hi = 0.0, lo = 0.0, locH[kSeg], locL[kSeg];
 #pragma unroll
             for (int i = 0; i < kSeg; ++i) {
@@ -1153,6 +1164,26 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 run += arr[k];
                 arr[k] = (unsigned short)run;
             }
+        };
+        // ... of a 1024-line block, sixteen counts (eight words) per lane in registers: a prefix inside each word, the running
+        // total added to both halves (counts <= 461 < 2^16), the lanes' totals scanned with DPP.  (Entry M -- maskers no line
+        // sees -- is not read after the scan and stays as it is.)
+        [[maybe_unused]] auto scan_counts_1024 = [&](unsigned short* arr) {
+            unsigned* w = reinterpret_cast<unsigned*>(arr) + 8 * lane;
+            unsigned x[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = w[j];
+            unsigned carry = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                unsigned v = x[j] + (x[j] << 16);
+                v += carry * 0x10001u;
+                x[j] = v;
+                carry = v >> 16;
+            }
+            const unsigned before = (unsigned)(wave_incl_scan((int)carry, lane) - (int)carry) * 0x10001u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = x[j] + before;
         };
         // The node terms, a masker per thread: lambda_r(theta) in product form (prefix x suffix products of theta - j), the two
         // 2^x, the R terms and the two error-bound terms; the four maskers of a row are lanes 4 j .. 4 j + 3 of a wave and
@@ -1230,20 +1261,28 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
             if (useNodes) {                              // (workgroup-uniform)
                 // the node terms by every wave, then -- behind one barrier -- the scan over their rows (one wave) BESIDE the
                 // other scans on the other waves
+                MRC_PHASE(13);
                 if (!(MRC_PROFILE_NODESKIP & 1)) node_terms();
+                MRC_PHASE(14);
                 __syncthreads();
+                MRC_PHASE(15);
+                using SegN = std::integral_constant<int, kSegNodes>;
                 if (waveU == 1) { if (!(MRC_PROFILE_NODESKIP & 1)) node_scan(); }      // (not the wave of the maskers beyond the first NT)
-                else if (waveU == 2) scan_pi();
-                else if (waveU == 3) { scan_counts(cntArr); scan_sc(); }
-                else scan_counts(nUpArr);
+                else if (waveU == 2) scan_pi(SegN{});
+                else if (waveU == 3) scan_sc(SegN{});
+                else if constexpr (DIM == 1024) { scan_counts_1024(cntArr); scan_counts_1024(nUpArr); }
+                else { scan_counts(cntArr); scan_counts(nUpArr); }
                 scansDone = true;
+                MRC_PHASE(9);                            // (profiling build: the slot of the sorted sweep's near field)
             }
         }
         if (!scansDone) {
             // four independent scans, dealt to the workgroup's waves (4 waves: one each; 2 waves: two each)
             for (int task = waveU; task < 4; task += NT / kWave) {
-                if (task == 0) scan_sc();
-                else if (task == 1) scan_pi();
+                using SegA = std::integral_constant<int, kSegAny>;
+                if (task == 0) scan_sc(SegA{});
+                else if (task == 1) scan_pi(SegA{});
+                else if constexpr (DIM == 1024) scan_counts_1024(task == 2 ? cntArr : nUpArr);
                 else scan_counts(task == 2 ? cntArr : nUpArr);
             }
         }
@@ -1458,6 +1497,10 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     }
     __syncthreads();
     MRC_PHASE(11);
+#ifdef MRC_PROFILE_PHASES
+    __syncthreads();
+    if (tid < 16 && (blockIdx.x & 63) == 0) atomicAdd(&gPhaseCycles[tid], tid == 7 ? 1ull : sPhase_[tid]);   // [7]: workgroups sampled
+#endif
     for (int bnd = tid; bnd < S.nBands; bnd += NT) {
         double v = bandKey[bnd] ? order_value(bandKey[bnd]) : -1e300;              // lines on the SPL floor / EXACT
         if (!EXACT && ratioKey[bnd]) {

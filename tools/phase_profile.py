@@ -5,7 +5,7 @@ PROFILING build of the library (make -C mrcaudiocodec_amd/csrc OUT=.../libmrc_hi
 EXTRA=-DMRC_PROFILE_PHASES).  Run as
     MRC_HIP_LIBRARY=mrcaudiocodec_amd/libmrc_hip_prof.so python tools/phase_profile.py [frames]
 The timers serialise each phase (s_memtime + wait), so the total is a few % above the production kernel; the
-FRACTIONS are what this is for.  Mono white noise, long blocks (the bench workload).
+FRACTIONS are what this is for.  Mono white noise as int16 PCM, long blocks (the bench workload).
 """
 import ctypes as C
 import json
@@ -17,18 +17,18 @@ import torch                                                    # noqa: E402
 from mrcaudiocodec_amd import _lib                              # noqa: E402
 from mrcaudiocodec_amd.batch import StreamEncoder               # noqa: E402
 
-NAMES = ["load+hann", "fft", "real split + intensity", "peak scan + compaction", "masker table + searches",
-         "suffix/prefix sums + count scan", "chunk setup", "far field", "direct pairs", "partial pairs",
-         "in-band + lower + log10 + band max", "final store"]
+NAMES = ["0 load + hann", "1 fft", "2 real split + intensity", "3 peak flags + compaction", "4 masker table + searches",
+         "5 scans done -> barrier", "6 chunk set-up", "7 (workgroups sampled)", "8 node evaluation of a chunk",
+         "9 the scans (rows | in-band | counts)", "10 ratio + band maxima", "11 wait for the other waves + final store",
+         "12 masker table -> barrier", "13 decision (slope range, node spacing)", "14 node terms", "15 node terms -> barrier"]
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 dev = torch.device("cuda", 0)
 enc = StreamEncoder(device_id=0)
 g = torch.Generator(device=dev)
 g.manual_seed(1234)
-p = torch.clamp(torch.round(torch.randn(((F + 1) * 1024,), generator=g, device=dev, dtype=torch.float64) * (0.1 * 32767)),
-                -32767, 32767)
-x = (torch.sign(p) * 2.0 * torch.abs(p) / 65535).contiguous()
+x = torch.clamp(torch.round(torch.randn(((F + 1) * 1024,), generator=g, device=dev, dtype=torch.float64) * (0.1 * 32767)),
+                -32767, 32767).to(torch.int16).contiguous()          # the bench's input: int16 PCM codes
 fn = _lib.lib.mrc_debug_phase_cycles
 fn.restype = C.c_int
 buf = (C.c_ulonglong * 16)()
@@ -37,7 +37,9 @@ assert fn(buf, 1) == 0
 enc.encode_long(x, None, F)
 assert fn(buf, 1) == 0
 cyc = list(buf)[:len(NAMES)]
+cyc[7] = 0
+units = max(int(buf[7]), 1)                                    # workgroups sampled (every 64th)
 tot = float(sum(cyc))
-print(json.dumps({"frames": F, "wave_cycles_per_frame": round(tot / F, 1),
-                  "phases": {n: {"cycles_per_frame": round(c / F, 1), "frac": round(c / tot, 4)} for n, c in zip(NAMES, cyc)}},
+print(json.dumps({"frames": F, "workgroups_sampled": units, "wave_cycles_per_frame": round(tot / units, 1),
+                  "phases": {n: {"cycles_per_frame": round(c / units, 1), "frac": round(c / tot, 4)} for n, c in zip(NAMES, cyc)}},
                  indent=1))
