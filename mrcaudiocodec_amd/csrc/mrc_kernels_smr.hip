@@ -501,7 +501,8 @@ constexpr double kNodeHMax = 0.22;                   // node spacing, bit per Ba
 constexpr double kNodeHMin = 1e-3;
 constexpr int kNodeMinMaskers = 32;
 constexpr int kNodeC = 4;                            // maskers per row of the prefix sums (a quad of lanes)
-constexpr int kNodeSeg = 26;                         // rows per lane in the scan over the rows (three lanes per column)
+constexpr int kNodeScanSegs = 7;                     // the scan over the rows: two waves, nine columns each, seven lanes per column
+constexpr int kNodeSeg = 11;                         // ... rows per lane (78 rows / 7 lanes)
 constexpr double kNodeTol = 1e-13;                   // accepted bound on the error of a line's masked intensity (relative)
 constexpr double kNodeRoundEps = 8.0 * 0x1p-53;      // K eps: K = 8 covers the measured rounding (tools/rank_proto2.py: <= 1.1)
 constexpr double kExpMinus16 = 1.1253517471925912e-07;
@@ -661,7 +662,7 @@ __device__ __attribute__((noinline)) double upper_cold(const double* mt, const d
 // profiling build only (make EXTRA=-DMRC_PROFILE_PHASES): shader-clock cycles per kernel phase, summed over the waves of
 // every 64th workgroup (per workgroup in LDS, flushed once at its end: an atomic to global memory per marker from every wave
 // made the build sixteen times slower than the kernel it was meant to describe)
-__device__ unsigned long long gPhaseCycles[16];
+__device__ unsigned long long gPhaseCycles[32];
 #define MRC_PHASE(i)                                                                  \
     do {                                                                              \
         const long long now_ = __builtin_readcyclecounter();                          \
@@ -769,8 +770,8 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     double* piLo = piHi + (last / 2 + 2);                //   the masker intensities, double-double (hi, lo)
 
 #ifdef MRC_PROFILE_PHASES
-    __shared__ unsigned long long sPhase_[16];
-    if (threadIdx.x < 16) sPhase_[threadIdx.x] = 0ull;
+    __shared__ unsigned long long sPhase_[32];
+    if (threadIdx.x < 32) sPhase_[threadIdx.x] = 0ull;
     __syncthreads();
     long long tPhase_ = __builtin_readcyclecounter();
 #endif
@@ -803,6 +804,7 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     const bool pairAligned = !(off & 1) && !(reinterpret_cast<uintptr_t>(chL) & (2 * sizeof(SampleT) - 1)) &&
                              (!chR || !(reinterpret_cast<uintptr_t>(chR) & (2 * sizeof(SampleT) - 1)));
     // long blocks: a thread's four samples are the inputs of its first butterfly and stay in registers (fft_regs_1024)
+    MRC_PHASE(16);
     constexpr bool kFftRegs = LONG && NT == 256 && kPre == 4;
     [[maybe_unused]] double2 fftIn[4];
     [[maybe_unused]] Tw3 fftW1;
@@ -884,6 +886,7 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
             }
         }
     }
+    MRC_PHASE(20);
     __syncthreads();                                    // T (in A or B) is dead from here on
     MRC_PHASE(2); MRC_STOP(2);
     if (!EXACT) {                                       // stage the Bark grid and the log10 table (used after 2 barriers)
@@ -939,7 +942,9 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     }
     const int incl = wave_incl_scan(mine, lane);
     if (lane == kWave - 1) waveCnt[wave] = incl;
+    MRC_PHASE(17);
     __syncthreads();
+    MRC_PHASE(18);
     int before = incl - mine, nPeaks = 0;
     for (int w = 0; w < NT / kWave; ++w) {
         const int c = waveCnt[w];
@@ -960,6 +965,7 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         unsigned long long* z = reinterpret_cast<unsigned long long*>(cntArr);
         for (int k = tid; k < (M + 2) / 2; k += NT) z[k] = 0ull;
     }
+    MRC_PHASE(19);
     __syncthreads();
     MRC_PHASE(3); MRC_STOP(3);
     double slLo = 1e300, slHi = -1e300;                 // this thread's maskers: range of the upper slope
@@ -1228,14 +1234,17 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 }
             }
         };
-        // Row totals -> prefix sums, in place, by one wave: lane = (column, third of the rows); a lane loads its <= 26 rows of the
-        // column at once, sums them up in registers, the three thirds of a column exchange their totals through ds_bpermute.
-        [[maybe_unused]] auto node_scan = [&]() {
+        // Row totals -> prefix sums, in place, by two waves (nine columns each): lane = (seventh of the rows, column); a lane loads
+        // its <= 11 rows of the column at once and sums them up in registers; the sevenths of a column get the totals below them
+        // by a shift and a three-step scan through ds_bpermute (lane - 9 d holds the same column, d sevenths lower).
+        [[maybe_unused]] auto node_scan = [&](int half) {
+            static_assert(kNodeCols == 18 && kNodeScanSegs * 9 <= kWave, "columns of the row scan");
+            static_assert((node_max_maskers(1024) + kNodeC - 1) / kNodeC <= kNodeScanSegs * kNodeSeg, "rows of the row scan");
             const int nR = (nPeaks + kNodeC - 1) / kNodeC;               // rows 1 .. nR hold totals; row q becomes sum_{m < 4 q}
-            const int L = (nR + 2) / 3;
-            const int seg = (lane >= kNodeCols ? 1 : 0) + (lane >= 2 * kNodeCols ? 1 : 0) + (lane >= 3 * kNodeCols ? 1 : 0);
-            const int col = lane - seg * kNodeCols;
-            const bool live = seg < 3;
+            const int L = (nR + kNodeScanSegs - 1) / kNodeScanSegs;      // <= kNodeSeg
+            const int seg = (lane * 57) >> 9;                            // lane / 9 for lane < 64
+            const int col = 9 * half + (lane - 9 * seg);
+            const bool live = seg < kNodeScanSegs;
             double v[kNodeSeg];
 #pragma unroll
             for (int i = 0; i < kNodeSeg; ++i) {
@@ -1245,11 +1254,17 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
 #pragma unroll
             for (int i = 1; i < kNodeSeg; ++i) v[i] += v[i - 1];
             const double tot = v[kNodeSeg - 1];
-            const int tlo = __double2loint(tot), thi = __double2hiint(tot);
-            const double t0 = __hiloint2double(__builtin_amdgcn_ds_bpermute(4 * col, thi), __builtin_amdgcn_ds_bpermute(4 * col, tlo));
-            const double t1 = __hiloint2double(__builtin_amdgcn_ds_bpermute(4 * (col + kNodeCols), thi),
-                                               __builtin_amdgcn_ds_bpermute(4 * (col + kNodeCols), tlo));
-            const double off = (seg >= 1 ? t0 : 0.0) + (seg >= 2 ? t1 : 0.0);
+            // the totals BELOW a seventh: an inclusive scan of the totals shifted up by one seventh.  (Not "inclusive minus
+            // own": the rows grow by 2^6 .. 2^9 per Bark, and the small sum of the lower rows would be lost in the subtraction.)
+            auto from_below = [&](double x, int d) {
+                const int from = 4 * (lane - 9 * d);
+                const double y = __hiloint2double(__builtin_amdgcn_ds_bpermute(from, __double2hiint(x)),
+                                                  __builtin_amdgcn_ds_bpermute(from, __double2loint(x)));
+                return seg >= d ? y : 0.0;
+            };
+            double off = from_below(tot, 1);
+#pragma unroll
+            for (int d = 1; d < kNodeScanSegs; d *= 2) off += from_below(off, d);
 #pragma unroll
             for (int i = 0; i < kNodeSeg; ++i) {
                 const int r = 1 + seg * L + i;
@@ -1259,21 +1274,26 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         bool scansDone = false;
         if constexpr (kNodes) {
             if (useNodes) {                              // (workgroup-uniform)
-                // the node terms by every wave, then -- behind one barrier -- the scan over their rows (one wave) BESIDE the
-                // other scans on the other waves
+                // The node terms by every wave; the scans that need the masker table only follow on waves 1 .. 3 without a
+                // barrier -- while wave 0 builds the terms of the maskers beyond the first NT (more than half of the frames
+                // of noise have some) -- and the scan over the rows, which needs every wave's terms, comes behind the barrier on
+                // two waves.  (What a barrier-delimited phase costs is its LONGEST wave: the others hold their slots idle.)
                 MRC_PHASE(13);
                 if (!(MRC_PROFILE_NODESKIP & 1)) node_terms();
                 MRC_PHASE(14);
+                using SegN = std::integral_constant<int, kSegNodes>;
+                if (waveU == 1) scan_pi(SegN{});
+                else if (waveU == 2) {
+                    scan_sc(SegN{});
+                    if constexpr (DIM == 1024) scan_counts_1024(cntArr); else scan_counts(cntArr);
+                } else if (waveU == 3) {
+                    if constexpr (DIM == 1024) scan_counts_1024(nUpArr); else scan_counts(nUpArr);
+                }
+                MRC_PHASE(9);                            // (profiling build: the slot of the sorted sweep's near field)
                 __syncthreads();
                 MRC_PHASE(15);
-                using SegN = std::integral_constant<int, kSegNodes>;
-                if (waveU == 1) { if (!(MRC_PROFILE_NODESKIP & 1)) node_scan(); }      // (not the wave of the maskers beyond the first NT)
-                else if (waveU == 2) scan_pi(SegN{});
-                else if (waveU == 3) scan_sc(SegN{});
-                else if constexpr (DIM == 1024) { scan_counts_1024(cntArr); scan_counts_1024(nUpArr); }
-                else { scan_counts(cntArr); scan_counts(nUpArr); }
+                if (!(MRC_PROFILE_NODESKIP & 1) && (waveU == 2 || waveU == 3)) node_scan(waveU - 2);
                 scansDone = true;
-                MRC_PHASE(9);                            // (profiling build: the slot of the sorted sweep's near field)
             }
         }
         if (!scansDone) {
@@ -1499,7 +1519,7 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
     MRC_PHASE(11);
 #ifdef MRC_PROFILE_PHASES
     __syncthreads();
-    if (tid < 16 && (blockIdx.x & 63) == 0) atomicAdd(&gPhaseCycles[tid], tid == 7 ? 1ull : sPhase_[tid]);   // [7]: workgroups sampled
+    if (tid < 32 && (blockIdx.x & 63) == 0) atomicAdd(&gPhaseCycles[tid], tid == 31 ? 1ull : sPhase_[tid]);   // [31]: workgroups sampled
 #endif
     for (int bnd = tid; bnd < S.nBands; bnd += NT) {
         double v = bandKey[bnd] ? order_value(bandKey[bnd]) : -1e300;              // lines on the SPL floor / EXACT
@@ -1721,11 +1741,11 @@ extern "C" int mrc_debug_node_stats(unsigned long long* out4, int reset) {
 #endif
 
 #ifdef MRC_PROFILE_PHASES
-extern "C" int mrc_debug_phase_cycles(unsigned long long* out16, int reset) {
+extern "C" int mrc_debug_phase_cycles(unsigned long long* out32, int reset) {
     hipError_t e = hipDeviceSynchronize();
-    if (e == hipSuccess) e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(gPhaseCycles), sizeof(unsigned long long) * 16);
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out32, HIP_SYMBOL(gPhaseCycles), sizeof(unsigned long long) * 32);
     if (e == hipSuccess && reset) {
-        unsigned long long z[16] = {};
+        unsigned long long z[32] = {};
         e = hipMemcpyToSymbol(HIP_SYMBOL(gPhaseCycles), z, sizeof z);
     }
     return e == hipSuccess ? 0 : -1;
