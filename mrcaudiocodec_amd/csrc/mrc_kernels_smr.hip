@@ -975,6 +975,7 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         const double x0 = xi[p - 1], x1 = xi[p], x2 = xi[p + 1];
         {
             double s3 = (x0 + x1) + x2;
+            MRC_PHASE(21);
             double level = EXACT ? spl_db(s3) : spl_db_tab(s3, logTabLds);   // psychoac.py:164
             const double fnum = S.binHz * (((p - 1) * x0 + p * x1) + (p + 1) * x2);
             double fm = EXACT ? fnum / s3 : fnum * recip_nr(s3);                  // psychoac.py:165
@@ -1008,14 +1009,41 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 // The searches start from the precomputed answers for the line nearest to the masker's own
                 // frequency and walk to the exact boundary (a step or two; any start gives the same result).
                 const int kNear = min(max((int)(fm * S.linesPerHz), 0), M - 1);
+                MRC_PHASE(22);
                 int lo = S.loLine[kNear], hi = S.hiLine[kNear];
-                while (lo > 0 && zbS[lo - 1] - zm >= -0.5) --lo;
-                while (lo < M && !(zbS[lo] - zm >= -0.5)) ++lo;
+#ifdef MRC_PROFILE_PHASES
+                asm volatile("" : "+v"(lo), "+v"(hi));
+#endif
+                MRC_PHASE(23);
+                // The hints are the answers for the Bark value of line kNear, less than a line away from z_m: the boundary
+                // is the hinted line or a neighbour.  Both windows (hint - 2 .. hint + 1) are read at once and decided in
+                // registers -- one LDS round trip instead of one per step of four dependent loops; whoever is not settled by
+                // that (never, on the corpora of the tests) walks as before.
+                {
+                    auto zAt = [&](int k) { return zbS[min(max(k, 0), M - 1)]; };
+                    const double a0 = zAt(lo - 2), a1 = zAt(lo - 1), a2 = zAt(lo), a3 = zAt(lo + 1);
+                    const double b0 = zAt(hi - 2), b1 = zAt(hi - 1), b2 = zAt(hi), b3 = zAt(hi + 1);
+                    // (line M stands for "no line": the predicate holds there; below line 0 it does not)
+                    auto sees = [&](double zv, int k) { return k >= M || (k >= 0 && zv - zm >= -0.5); };
+                    auto above = [&](double zv, int k) { return k >= M || (k >= 0 && zv - zm > 0.5); };
+                    const bool s0 = sees(a0, lo - 2), s1 = sees(a1, lo - 1), s2 = sees(a2, lo), s3 = sees(a3, lo + 1);
+                    const bool u0 = above(b0, hi - 2), u1 = above(b1, hi - 1), u2 = above(b2, hi), u3 = above(b3, hi + 1);
+                    const int first = (s1 && !s0) ? lo - 1 : (s2 && !s1) ? lo : (s3 && !s2) ? lo + 1 : -1;
+                    const int over = (u1 && !u0) ? hi - 1 : (u2 && !u1) ? hi : (u3 && !u2) ? hi + 1 : -1;
+                    if (__any(first < 0 || over < 0)) {
+                        while (lo > 0 && zbS[lo - 1] - zm >= -0.5) --lo;
+                        while (lo < M && !(zbS[lo] - zm >= -0.5)) ++lo;
+                        hi = max(hi, lo);
+                        while (hi > 0 && zbS[hi - 1] - zm > 0.5) --hi;
+                        while (hi < M && !(zbS[hi] - zm > 0.5)) ++hi;
+                    } else {
+                        lo = first;
+                        hi = over;
+                    }
+                }
                 atomicAdd(reinterpret_cast<unsigned int*>(cntArr) + (lo >> 1), 1u << (16 * (lo & 1)));
-                lo = max(hi, lo);
-                while (lo > 0 && zbS[lo - 1] - zm > 0.5) --lo;
-                while (lo < M && !(zbS[lo] - zm > 0.5)) ++lo;
-                atomicAdd(reinterpret_cast<unsigned int*>(nUpArr) + (lo >> 1), 1u << (16 * (lo & 1)));
+                atomicAdd(reinterpret_cast<unsigned int*>(nUpArr) + (hi >> 1), 1u << (16 * (hi & 1)));
+                MRC_PHASE(24);
             }
         }
     }

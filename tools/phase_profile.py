@@ -22,7 +22,8 @@ NAMES = ["0 samples + Hann (wait for the loads)", "1 fft", "2 real split -> barr
          "9 the scans (rows | in-band | counts)", "10 ratio + band maxima", "11 wait for the other waves",
          "12 masker table -> barrier", "13 decision (slope range, node spacing)", "14 node terms", "15 node terms -> barrier",
          "16 prologue (arguments, unit, keys)", "17 peak flags + count", "18 counts -> barrier", "19 compaction + histogram zeroing",
-         "20 real split + intensity"] + ["-"] * 11
+         "20 real split + intensity", "21 masker: peak bin + its three intensities", "22 masker: level, frequency, Bark, intensity, constants",
+         "23 masker: search hints (global)", "24 masker: the two walks + histogram"] + ["-"] * 7
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 dev = torch.device("cuda", 0)
