@@ -1302,25 +1302,37 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         bool scansDone = false;
         if constexpr (kNodes) {
             if (useNodes) {                              // (workgroup-uniform)
-                // The node terms by every wave; the scans that need the masker table only follow on waves 1 .. 3 without a
-                // barrier -- while wave 0 builds the terms of the maskers beyond the first NT (more than half of the frames
-                // of noise have some) -- and the scan over the rows, which needs every wave's terms, comes behind the barrier on
-                // two waves.  (What a barrier-delimited phase costs is its LONGEST wave: the others hold their slots idle.)
+                // The node terms by every wave.  With more than NT maskers (more than half of the frames of noise) wave 0 builds
+                // the terms of the rest in a second round: the scans that need the masker table only then follow on waves
+                // 1 .. 3 without a barrier, and the scan over the rows, which needs every wave's terms, comes behind the barrier
+                // on two waves.  Otherwise all scans run side by side behind the barrier.  (What a barrier-delimited phase
+                // costs is its LONGEST wave: the others hold their slots idle.)
                 MRC_PHASE(13);
                 if (!(MRC_PROFILE_NODESKIP & 1)) node_terms();
                 MRC_PHASE(14);
                 using SegN = std::integral_constant<int, kSegNodes>;
-                if (waveU == 1) scan_pi(SegN{});
-                else if (waveU == 2) {
-                    scan_sc(SegN{});
-                    if constexpr (DIM == 1024) scan_counts_1024(cntArr); else scan_counts(cntArr);
-                } else if (waveU == 3) {
-                    if constexpr (DIM == 1024) scan_counts_1024(nUpArr); else scan_counts(nUpArr);
+                auto counts = [&](unsigned short* arr) {
+                    if constexpr (DIM == 1024) scan_counts_1024(arr); else scan_counts(arr);
+                };
+#ifndef MRC_SCAN_HYBRID
+#define MRC_SCAN_HYBRID 1
+#endif
+                if (!MRC_SCAN_HYBRID || nPeaks > NT) {   // (workgroup-uniform) wave 0 has had a second round of terms
+                    if (waveU == 1) scan_pi(SegN{});
+                    else if (waveU == 2) { scan_sc(SegN{}); counts(cntArr); }
+                    else if (waveU == 3) counts(nUpArr);
+                    MRC_PHASE(9);                        // (profiling build: the slot of the sorted sweep's near field)
+                    __syncthreads();
+                    MRC_PHASE(15);
+                    if (!(MRC_PROFILE_NODESKIP & 1) && (waveU == 2 || waveU == 3)) node_scan(waveU - 2);
+                } else {                                 // every wave is through with its terms at the same time
+                    __syncthreads();
+                    MRC_PHASE(15);
+                    if (waveU < 2) { if (!(MRC_PROFILE_NODESKIP & 1)) node_scan(waveU); }
+                    else if (waveU == 2) scan_pi(SegN{});
+                    else { scan_sc(SegN{}); counts(cntArr); counts(nUpArr); }
+                    MRC_PHASE(9);
                 }
-                MRC_PHASE(9);                            // (profiling build: the slot of the sorted sweep's near field)
-                __syncthreads();
-                MRC_PHASE(15);
-                if (!(MRC_PROFILE_NODESKIP & 1) && (waveU == 2 || waveU == 3)) node_scan(waveU - 2);
                 scansDone = true;
             }
         }
@@ -1377,9 +1389,11 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         // orders below what the FFT in front of it already differs by).  Lines on the floor, and every line when
         // the caller wants the thresholds themselves, take the reference's formula.
         // (a2 of a line: the intensity of its own MDCT line, psychoac.py:212)
+        // = 2 xs^2 / (1/2) with xs = x 2^scale (codecThem.py:323; psychoac.py:212): the factors of two commute with the one
+        // rounding of the square, so the square of 2 xs is the same double
         auto line_a2 = [&](const LineConst& cur) {
-            const double xs = ldexp(cur.x, scale);                           // codecThem.py:323 (exact)
-            return 2. * (xs * xs) / (1. / 2.);
+            const double xs2 = ldexp(cur.x, scale + 1);
+            return xs2 * xs2;
         };
         auto line_plain = [&](double a2, double t) { return thresh != nullptr || !(a2 >= kSplFloorGuard && t >= kSplFloorGuard); };
         // noPlain: the caller has checked that no lane of the chunk takes the reference's formula (no call in its loop)
