@@ -805,7 +805,11 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                              (!chR || !(reinterpret_cast<uintptr_t>(chR) & (2 * sizeof(SampleT) - 1)));
     // long blocks: a thread's four samples are the inputs of its first butterfly and stay in registers (fft_regs_1024)
     MRC_PHASE(16);
+#ifndef MRC_SPLIT_PAIRS
+#define MRC_SPLIT_PAIRS 1
+#endif
     constexpr bool kFftRegs = LONG && NT == 256 && kPre == 4;
+    constexpr bool kSplitPairs = kFftRegs && MRC_SPLIT_PAIRS;
     [[maybe_unused]] double2 fftIn[4];
     [[maybe_unused]] Tw3 fftW1;
     if constexpr (kFftRegs) fftW1 = fft1024_twiddles(S.fftTw, 1, tid);
@@ -836,7 +840,8 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                                                         // the 256-entry one is being staged)
 #pragma unroll
     for (int u = 0; u < kPre; ++u) {
-        wnPre[u] = S.wN[min(tid + u * NT, last - 1)];
+        // (long blocks: the real split below works on the pairs (k, H - k), k = tid + 1, tid + 1 + NT)
+        if (!kSplitPairs || u < 2) wnPre[u] = S.wN[kSplitPairs ? tid + 1 + u * NT : min(tid + u * NT, last - 1)];
         zbPre[u] = EXACT ? 0.0 : S.zb[min(tid + u * NT, M - 1)];
     }
     if (!EXACT) {
@@ -865,6 +870,31 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
         T = fft_lds_global<NT>(A, B, H, S.radH, S.nRadH, S.wH, tid);
     }
     MRC_PHASE(1); MRC_STOP(1);
+    if constexpr (kSplitPairs) {
+        // Bins k and H - k come from the same two values of T: with Xe = (T[k] + conj T[H-k]) / 2, Xo = (T[k] - conj T[H-k]) / 2i
+        // and P = w_k Xo, X[k] = Xe + P and X[H-k] = conj(Xe - P) (w_{H-k} = -conj w_k).  A thread takes two pairs -- half the
+        // reads of T and one complex product for two bins; bin k exactly as below, bin H - k as below with the mirrored twiddle.
+        auto intensity = [&](double2 X) {
+            return EXACT ? 4. * (X.x * X.x + X.y * X.y) / S.xiDen : (4. * (X.x * X.x + X.y * X.y)) * xiInv;   // psychoac.py:151
+        };
+        auto split = [&](int k, double2 w, bool both) {
+            const double2 zk = T[k];
+            double2 zc = T[(H - k) & (H - 1)];
+            zc.y = -zc.y;
+            const double2 ev = make_double2(0.5 * (zk.x + zc.x), 0.5 * (zk.y + zc.y));
+            const double2 d = make_double2(zk.x - zc.x, zk.y - zc.y);
+            const double2 od = make_double2(0.5 * d.y, -0.5 * d.x);
+            const double2 P = cmul(w, od);
+            xi[k] = intensity(make_double2(P.x + ev.x, P.y + ev.y));
+            if (both) xi[H - k] = intensity(make_double2(ev.x - P.x, ev.y - P.y));
+        };
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int k = tid + 1 + u * NT;              // 1 .. H / 2
+            split(k, wnPre[u], H - k < last && k != H / 2);
+        }
+        if (tid == 0) split(0, make_double2(1.0, 0.0), false);
+    } else
     for (int k0 = tid; k0 < last; k0 += NT * kPre) {
         double2 wn[kPre];
 #pragma unroll
