@@ -315,26 +315,38 @@ __device__ __forceinline__ Tw3 fft1024_twiddles(const double2* __restrict__ tw, 
     const double2* src = tw + base + 3 * (tid & (p - 1));
     return Tw3{{src[0], src[1], src[2]}};
 }
+// The outputs of the first two passes are written at strides of 4 and 16 entries (of 16 bytes: eight entries span the 32
+// banks): without a twist, eight neighbouring lanes would fall on two / four bank groups.  MRC_FFT_TWIST moves entry j of
+// the first pass's output to j ^ ((j >> 3) & 3) and entry j of the second's to j ^ (((j >> 4) & 1) << 2): the writes of eight
+// lanes then cover all banks, and the next pass's reads of eight CONSECUTIVE entries see a permutation of those eight.
+#ifndef MRC_FFT_TWIST
+#define MRC_FFT_TWIST 1
+#endif
 template <int P>
 __device__ __forceinline__ void fft1024_pass(const double2* __restrict__ in, double2* __restrict__ out, const Tw3& W, int tid) {
     constexpr int lp = P == 4 ? 2 : P == 16 ? 4 : P == 64 ? 6 : 8;
     const int k = tid & (P - 1);
     const int j = (tid >> lp) * (P * 4) + k;
+    int from = tid;
+    if (MRC_FFT_TWIST && P == 4) from = tid ^ ((tid >> 3) & 3);
+    if (MRC_FFT_TWIST && P == 16) from = tid ^ (((tid >> 4) & 1) << 2);
+    const int flip = (MRC_FFT_TWIST && P == 4) ? (tid >> 2) & 1 : 0;
     double2 u[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) u[r] = in[tid + r * 256];
+    for (int r = 0; r < 4; ++r) u[r] = in[from + r * 256];
 #pragma unroll
     for (int r = 1; r < 4; ++r) u[r] = cmul(u[r], W.w[r - 1]);
     butterfly<4>(u);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) out[j + q * P] = u[q];
+    for (int q = 0; q < 4; ++q) out[j + (q ^ flip) * P] = u[q];
 }
 // u: in[tid + r 256], r = 0..3; 256 threads.  Returns the buffer with the natural-order result (A).
 __device__ __forceinline__ double2* fft_regs_1024(double2 (&u)[4], double2* A, double2* B, const double2* __restrict__ tw,
                                                   Tw3 w1, int tid) {
     butterfly<4>(u);                                     // pass p = 1: unit twiddles
+    const int twist = MRC_FFT_TWIST ? (tid >> 1) & 3 : 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) B[4 * tid + q] = u[q];
+    for (int q = 0; q < 4; ++q) B[4 * tid + (q ^ twist)] = u[q];
     Tw3 w2 = fft1024_twiddles(tw, 2, tid);
     __syncthreads();
     fft1024_pass<4>(B, A, w1, tid);
