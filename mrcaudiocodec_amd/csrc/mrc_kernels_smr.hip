@@ -1018,8 +1018,8 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
             const double lvl15 = level - 15.0;                               // psychoac.py:42-43 (tonal drop)
             const double boost = 0.37 * fmax(level - 40, 0.0);               // psychoac.py:76
             double* e = mt + 4 * before;
-            e[1] = zm;
             if (EXACT) {
+                e[1] = zm;
                 e[0] = lvl15;
                 e[2] = boost;
             } else {
@@ -1029,11 +1029,12 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 const double I = exp2_dd(eh, fma(xe, kLog2Of10, -eh) + xe * kLog2Of10Lo);
                 const double ph = kLowHi * zm;
                 const double pl = fma(kLowHi, zm, -ph) + kLowLo * zm;
-                e[0] = I;
-                e[2] = (((-27 + boost) * 0.1) * kLog2Of10) * (double)TAB;  // upper slope, 1/T bit per Bark
-                slLo = fmin(slLo, e[2]);
-                slHi = fmax(slHi, e[2]);
-                e[3] = I * exp2_dd(ph, pl);
+                // (the entry leaves as two 16-byte stores: 8-byte stores 32 bytes apart from lane to lane meet on four banks)
+                const double slope = (((-27 + boost) * 0.1) * kLog2Of10) * (double)TAB;  // upper slope, 1/T bit per Bark
+                slLo = fmin(slLo, slope);
+                slHi = fmax(slHi, slope);
+                reinterpret_cast<double2*>(e)[0] = make_double2(I, zm);
+                reinterpret_cast<double2*>(e)[1] = make_double2(slope, I * exp2_dd(ph, pl));
                 // first line that sees this masker at all (fl(z_k - z_m) >= -1/2) and first line more than
                 // 1/2 Bark above it (fl(z_k - z_m) > 1/2): both predicates are monotone in k
                 // The searches start from the precomputed answers for the line nearest to the masker's own
@@ -1261,7 +1262,8 @@ __device__ __forceinline__ void smr_body(DevShape S, int nsigArg, const SampleT*
                 const int m = base + lane;
                 const bool valid = m < nPeaks;
                 const int mm = min(m, nPeaks - 1);
-                const double I = valid ? mt[4 * mm] : 0.0, zm = mt[4 * mm + 1], sl = mt[4 * mm + 2];
+                const double2 Iz = *reinterpret_cast<const double2*>(mt + 4 * mm);       // (one 16-byte read: see the table's stores)
+                const double I = valid ? Iz.x : 0.0, zm = Iz.y, sl = mt[4 * mm + 2];
                 const double theta = (nodeS0 - sl) * invH;              // the masker's slope in node units, [margin, R-1-margin]
                 double suf[kNodeR];                                      // prod_{j > r} (theta - j)
                 suf[kNodeR - 1] = 1.0;
