@@ -34,6 +34,7 @@ struct DevShape {
     double budgetJointPre;           // codecThem.py:381-388 (before `+= bitReservoir`)
     double blkswA, blkswB;
     const double* win;               // [N] transition window (window.py:104-121)
+    int winSymmetric;                // win[n] == win[N - 1 - n] bit for bit (true for a = b)
     const double* hann;              // [N] window.py:28-45
     const double2* pre;              // [Q] exp(-i pi (4n+1)/(4M)), M = N/2
     const double2* post;             // [Q] exp(-i pi k / M)

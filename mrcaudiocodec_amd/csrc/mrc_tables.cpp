@@ -228,6 +228,11 @@ bool build_shape(const mrc_config& cfg, int a, int b, HostShape* out, std::strin
         for (int i = 0; i < b; ++i) win[a + i] = kb[b + i];
         for (int n = 0; n < N; ++n)                      // window.py:38-42
             hann[n] = 0.5 + (-0.5 * std::cos(((2.0 * M_PI) / N) * (n + 0.5)));
+        // a = b: the two halves are built from the same running sums in the same order, so win[n] == win[N - 1 - n] bit for
+        // bit; checked rather than assumed (mdct_long_kernel keeps only one half of the window in registers when it holds)
+        S.winSymmetric = 1;
+        for (int n = 0; n < N / 2; ++n)
+            if (std::memcmp(&win[n], &win[N - 1 - n], sizeof(double)) != 0) S.winSymmetric = 0;
     }
     // twiddles
     const int M = S.halfN;
