@@ -1802,6 +1802,59 @@ __global__ __launch_bounds__(kWave * kShortWaves) __attribute__((amdgpu_waves_pe
 
 }  // namespace
 
+// Two translation units.  The mono long-block kernel of the hot path -- smr_kernel<false, *, 256, 1024, 1>, 80 % of a
+// headline step -- gains 3 % from LLVM's max-ILP scheduling strategy; the joint variant <..., 2> LOSES 2 % with it (more
+// spills at the 128-register cap).  The strategy is a per-file option, so mrc_kernels_smr_mono.hip includes this file with
+// MRC_SMR_TU_MONO defined and compiles that one instantiation (launch_smr_mono_long); everything else stays here.
+// Diagnostics builds keep one unit: their counters are device globals of the unit that defines them.
+#if defined(MRC_NODE_STATS) || defined(MRC_PROFILE_PHASES)
+#define MRC_SMR_SPLIT 0
+#else
+#define MRC_SMR_SPLIT 1
+#endif
+#ifndef MRC_SMR_THREADS                          // workgroup size for blocks of more than 128 lines
+#define MRC_SMR_THREADS 256
+#endif
+hipError_t launch_smr_mono_long(const DevShape& S, int64_t nFrames, const void* chL, int fmt, int64_t stride,
+                                const int64_t* offsets, const double* lines, const int* oscale, double* smr,
+                                double* bandPeak, hipStream_t st, unsigned long long* sens);
+
+namespace {
+// dynamic LDS (doubles): FFT ping-pong [4H] + intensity spectrum [peakLast + 1].  The staged tables go into
+// areas that are dead when they are needed if there is room (the long block is sized for 4 workgroups per CU
+// and must not grow), else behind the spectrum.
+inline SmrLds smr_launch_layout(const DevShape& S, size_t* ldsBytes) {
+    int total = 0;
+    const SmrLds lay = smr_layout(S.H, S.halfN, S.peakLast, &total);
+#ifdef MRC_PROFILE_EXTRA_LDS                     // profiling aid: pad the workgroup's LDS (occupancy experiments)
+    total += MRC_PROFILE_EXTRA_LDS / 8;
+#endif
+    *ldsBytes = (size_t)total * sizeof(double);
+    return lay;
+}
+}  // namespace
+
+#ifdef MRC_SMR_TU_MONO
+#if MRC_SMR_SPLIT
+hipError_t launch_smr_mono_long(const DevShape& S, int64_t nFrames, const void* chL, int fmt, int64_t stride,
+                                const int64_t* offsets, const double* lines, const int* oscale, double* smr,
+                                double* bandPeak, hipStream_t st, unsigned long long* sens) {
+    size_t lds = 0;
+    const SmrLds lay = smr_launch_layout(S, &lds);
+    const dim3 grid((unsigned)nFrames);
+    if (fmt == kSampleI16)
+        hipLaunchKernelGGL((smr_kernel<false, short, 256, 1024, 1>), grid, dim3(256), lds, st, S, 1, (const short*)chL,
+                           (const short*)nullptr, stride, offsets, lines, oscale, smr, (double*)nullptr, bandPeak,
+                           (const int*)nullptr, lay, sens);
+    else
+        hipLaunchKernelGGL((smr_kernel<false, double, 256, 1024, 1>), grid, dim3(256), lds, st, S, 1, (const double*)chL,
+                           (const double*)nullptr, stride, offsets, lines, oscale, smr, (double*)nullptr, bandPeak,
+                           (const int*)nullptr, lay, sens);
+    return hipGetLastError();
+}
+#endif
+#else   // the main unit
+
 #ifdef MRC_NODE_STATS
 extern "C" int mrc_debug_node_stats(unsigned long long* out4, int reset) {
     hipError_t e = hipDeviceSynchronize();
@@ -1831,24 +1884,14 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
                       double* bandPeak, const int* msSwitch, bool exactSpread, hipStream_t st, unsigned long long* sens) {
     if (nFrames <= 0) return hipSuccess;
     const int nsig = chR ? 4 : 1;
-    // dynamic LDS (doubles): FFT ping-pong [4H] + intensity spectrum [peakLast + 1].  The staged tables go into
-    // areas that are dead when they are needed if there is room (the long block is sized for 4 workgroups per CU
-    // and must not grow), else behind the spectrum.
     const int H = S.H, M = S.halfN;
-    int total = 0;
-    const SmrLds lay = smr_layout(H, M, S.peakLast, &total);
-#ifdef MRC_PROFILE_EXTRA_LDS                     // profiling aid: pad the workgroup's LDS (occupancy experiments)
-    total += MRC_PROFILE_EXTRA_LDS / 8;
-#endif
-    const size_t lds = (size_t)total * sizeof(double);
+    size_t lds = 0;
+    const SmrLds lay = smr_launch_layout(S, &lds);
     // blocks of up to 128 lines (two 64-line chunks) run as two-wave workgroups: no idle waves holding CU wave slots
     const dim3 grid((unsigned)(nFrames * nsig));
 #define MRC_SMR_LAUNCH(EX, TY, THREADS, LG, MD)                                                                      \
     hipLaunchKernelGGL((smr_kernel<EX, TY, THREADS, LG, MD>), grid, dim3(THREADS), lds, st, S, nsig, (const TY*)chL, \
                        (const TY*)chR, stride, offsets, lines, oscale, smr, thresh, bandPeak, msSwitch, lay, sens)
-#ifndef MRC_SMR_THREADS                          // workgroup size for blocks of more than 128 lines
-#define MRC_SMR_THREADS 256
-#endif
     const bool isLong = H == 1024 && M == 1024 && S.peakLast == 924 && MRC_SMR_THREADS == 256 && lay.twOff >= 0;
     const bool isShort = H == 128 && M == 128 && S.peakLast == 28 && lay.twOff >= 0;
     const bool isTrans = H == 576 && M == 576 && S.peakLast == 476 && lay.twOff < 0 && MRC_SMR_THREADS == 256;
@@ -1870,10 +1913,15 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
 #undef MRC_SMR_SHORT
         return hipGetLastError();
     }
+#if MRC_SMR_SPLIT                                // (mode 1: mono, no switch, no thresholds -- the other unit's kernel)
+#define MRC_SMR_MONO_LONG(EX, TY) return launch_smr_mono_long(S, nFrames, chL, fmt, stride, offsets, lines, oscale, smr, bandPeak, st, sens)
+#else
+#define MRC_SMR_MONO_LONG(EX, TY) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 1024, 1)
+#endif
 #define MRC_SMR_PICK(EX, TY) do { if (isShort && !EX && mode == 1) MRC_SMR_LAUNCH(EX, TY, 128, 128, 1);               \
                                   else if (isShort && !EX) MRC_SMR_LAUNCH(EX, TY, 128, 128, 0);                      \
                                   else if (M <= 2 * kWave) MRC_SMR_LAUNCH(EX, TY, 128, 0, 0);                        \
-                                  else if (isLong && !EX && mode == 1) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 1024, 1);   \
+                                  else if (isLong && !EX && mode == 1) MRC_SMR_MONO_LONG(EX, TY);                    \
                                   else if (isLong && !EX && mode == 2) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 1024, 2);   \
                                   else if (isLong && !EX) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 1024, 0);          \
                                   else if (isTrans && !EX && mode == 1) MRC_SMR_LAUNCH(EX, TY, MRC_SMR_THREADS, 576, 1);   \
@@ -1882,8 +1930,10 @@ hipError_t launch_smr(const DevShape& S, int64_t nFrames, const void* chL, const
     if (fmt == kSampleI16) { if (exactSpread) MRC_SMR_PICK(true, short); else MRC_SMR_PICK(false, short); }
     else { if (exactSpread) MRC_SMR_PICK(true, double); else MRC_SMR_PICK(false, double); }
 #undef MRC_SMR_PICK
+#undef MRC_SMR_MONO_LONG
 #undef MRC_SMR_LAUNCH
     return hipGetLastError();
 }
+#endif  // the main unit
 
 }  // namespace mrc
