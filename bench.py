@@ -89,8 +89,13 @@ def latest_profile(suffix, tag=None):
     import glob
     import re
     pat = "*%s" % suffix if tag is None else "*%s*%s" % (tag, suffix)
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)),
-                   key=lambda f: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", os.path.basename(f))])
+    def order(f):
+        # newest round first in the key's last place; within a round the "_final_" set wins over mid-round states
+        b = os.path.basename(f)
+        m = re.match(r"r(\d+)_", b)
+        return (int(m.group(1)) if m else -1, "_final_" in b,
+                [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", b)])
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)), key=order)
     if not files:
         return None, None
     with open(files[-1]) as f:
