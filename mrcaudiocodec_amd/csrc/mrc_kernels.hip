@@ -11,6 +11,8 @@
 #include "mrc_device.hpp"
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 
 namespace mrc {
 using namespace dev;
@@ -184,9 +186,16 @@ __device__ __forceinline__ double wave_max4(double p0, double p1, double p2, dou
 
 constexpr int kMdctWaves = 4;                           // waves per workgroup, each with its own groups of units
 constexpr int kMdctMaxRun = 8;                          // groups per wave, at most
-template <class SampleT, int N, int U, int NSIG, bool SHIFT0>
-__global__ __launch_bounds__(kWave * kMdctWaves, 2) void mdct_wave_kernel(
-    DevShape S, int64_t nUnits, int run, const SampleT* __restrict__ chL, const SampleT* __restrict__ chR, int64_t stride,
+// K64 != 0 (transition blocks, N = 1152, shift = -+224): the fold N -> N/2 happens in REGISTERS.  The two samples that fold
+// into one DCT-IV input are n and (64 K64 + 63 - n) mod N (K64 = 15 for 1024 + 128, 1 for 128 + 1024), i.e. chunk c of 64
+// samples pairs with chunk (K64 - c) mod 18 read backwards: the second chunk of every pair is loaded with the lane order
+// reversed, the partners sit in the same lane, their signs (window wrap and fold) ride on the lane's window values, and only
+// the N/2 sums travel through LDS.  Same products, same two-term sums as the staged form (x - y = x + (-y) exactly): identical
+// lines.  9 instead of 13.5 KiB of LDS per wave and no shift bookkeeping: three workgroups per CU instead of two.
+template <int K64> __host__ __device__ constexpr int fold_partner(int c) { return (K64 - c + 18) % 18; }
+template <class SampleT, int N, int U, int NSIG, bool SHIFT0, int K64>
+__global__ __launch_bounds__(kWave * kMdctWaves, K64 ? 3 : 2) void mdct_wave_kernel(
+    DevShape S, int64_t nUnits, int64_t nWaves, const SampleT* __restrict__ chL, const SampleT* __restrict__ chR, int64_t stride,
     const int64_t* __restrict__ offsets, double* __restrict__ lines, int* __restrict__ oscale) {
     constexpr int Q = N / 4, M = N / 2;
     constexpr int kSlots = U * N / kWave;                // sample slots per lane: s = lane + 64 c, unit c / (N / 64)
@@ -194,23 +203,47 @@ __global__ __launch_bounds__(kWave * kMdctWaves, 2) void mdct_wave_kernel(
     constexpr int kPoints = (U * Q + kWave - 1) / kWave; // FFT points per lane: g = lane + 64 c
     // doubles per wave: y [U][N] (windowed samples; dead after the fold, then the FFT's second buffer B [U][Q] complex and,
     // for the sizes whose result ends in A, the staging of the output lines) | A [U][Q] complex (and the staging otherwise)
-    constexpr int kWaveLds = U * N + 2 * U * Q;
+    constexpr bool RF = K64 != 0;
+    constexpr int kWaveLds = RF ? 2 * U * M : U * N + 2 * U * Q;
     static_assert(N % kWave == 0 && ((U * Q) % kWave == 0 || U == 1), "a slot never straddles two units");
+    static_assert(!RF || (U == 1 && N == 1152 && !SHIFT0), "register fold: one transition block per wave");
     extern __shared__ double smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     double* y = smem + wave * kWaveLds;
-    double2* A = reinterpret_cast<double2*>(y + U * N);
+    double2* A = reinterpret_cast<double2*>(y + (RF ? U * M : U * N));
     double2* B = reinterpret_cast<double2*>(y);
     double2* wl = reinterpret_cast<double2*>(smem + kMdctWaves * kWaveLds);          // [Q] e^{-2 pi i t/Q}
     __shared__ long long sOff[kMdctWaves][kMdctMaxRun * U];                          // sample offset of every unit of a wave's run
-    for (int t = threadIdx.x; t < Q; t += kWave * kMdctWaves) wl[t] = S.wQ[t];
+    double2* preL = wl + Q;                             // register fold: pre- / post-twiddles in LDS too ([Q] each): the 40
+    double2* postL = preL + Q;                          // registers they would take are what keeps three waves on a SIMD
+    for (int t = threadIdx.x; t < Q; t += kWave * kMdctWaves) {
+        wl[t] = S.wQ[t];
+        if (RF) { preL[t] = S.pre[t]; postL[t] = S.post[t]; }
+    }
     // lane constants: window value of every sample slot and where the sample goes after the signed circular shift by
     // (b-a)/4 (see mdct_kernel; bit 31: negated; SHIFT0: a = b, no shift); pre- and post-twiddle of every point slot
     double wv[kSlots];
     unsigned dst[SHIFT0 ? 1 : kSlots];
 #pragma unroll
     for (int c = 0; c < kSlots; ++c) {
+        if (RF) {
+            // sample n of this lane's slot (second chunk of a pair: lanes reversed), where it lands after the signed circular
+            // shift (m), which DCT-IV input it folds into (j) and with which sign (mdct_kernel's fold, by quarter of m)
+            const bool first = c < fold_partner<K64>(c);
+            const int n = (first ? lane : kWave - 1 - lane) + kWave * c;
+            int m = n + S.shift;
+            bool neg = false;
+            if (m < 0) { m += N; neg = true; }
+            else if (m >= N) { m -= N; neg = true; }
+            int j;
+            if (m < Q) j = m + Q;
+            else if (m < 3 * Q) { j = 3 * Q - 1 - m; neg = !neg; }
+            else { j = m - 3 * Q; neg = !neg; }
+            wv[c] = neg ? -S.win[n] : S.win[n];
+            dst[SHIFT0 ? 0 : c] = (unsigned)j;
+            continue;
+        }
         const int n = lane + kWave * (c % kSlotsPerUnit);
         wv[c] = S.win[n];
         if (!SHIFT0) {
@@ -221,16 +254,22 @@ __global__ __launch_bounds__(kWave * kMdctWaves, 2) void mdct_wave_kernel(
             dst[SHIFT0 ? 0 : c] = (unsigned)(m + (c / kSlotsPerUnit) * N) | neg;
         }
     }
-    double2 preR[kPoints], postR[kPoints];
+    double2 preR[RF ? 1 : kPoints], postR[RF ? 1 : kPoints];
 #pragma unroll
-    for (int c = 0; c < kPoints; ++c) {
+    for (int c = 0; c < (RF ? 0 : kPoints); ++c) {
         const int n = min((lane + kWave * c) % Q, Q - 1);
         preR[c] = S.pre[n];
         postR[c] = S.post[n];
     }
     __syncthreads();                                    // twiddle table visible to all waves
 
-    const int64_t firstGroup = ((int64_t)blockIdx.x * kMdctWaves + wave) * run;
+    // the groups are dealt to the launch's nWaves wavefronts in contiguous runs that differ by at most one group (the host
+    // sizes nWaves so that the workgroups fill the chip a whole number of times and no run exceeds kMdctMaxRun)
+    const int64_t nGroups = (nUnits + U - 1) / U;
+    const int64_t waveId = (int64_t)blockIdx.x * kMdctWaves + wave;
+    if (waveId >= nWaves) return;                       // wave-uniform, after the workgroup's only barrier
+    const int64_t firstGroup = waveId * nGroups / nWaves;
+    const int run = (int)((waveId + 1) * nGroups / nWaves - firstGroup);
     // the sample offsets of all units of this wave's run, fetched at once (a scalar load per group inside the loop would put
     // a memory round trip in front of every group's sample loads)
     if (lane < run * U) {
@@ -246,16 +285,18 @@ __global__ __launch_bounds__(kWave * kMdctWaves, 2) void mdct_wave_kernel(
     auto request = [&](int it) {
 #pragma unroll
         for (int c = 0; c < kSlots; ++c) {
-            const int64_t i = sOff[wave][it * U + c / kSlotsPerUnit] + lane + kWave * (c % kSlotsPerUnit);
+            const int ln = (RF && c > fold_partner<K64>(c)) ? kWave - 1 - lane : lane;
+            const int64_t i = sOff[wave][it * U + c / kSlotsPerUnit] + ln + kWave * (c % kSlotsPerUnit);
             rawL[c] = chL[i];
             if (NSIG != 1) rawR[c] = chR[i];
         }
     };
-    if (firstGroup * U < nUnits) request(0);
+    if (run > 0) request(0);
     for (int it = 0; it < run; ++it) {
         const int64_t u0 = (firstGroup + it) * U;
         if (u0 >= nUnits) break;                        // wave-uniform
-        // ---- A. convert, window, shift
+        // ---- A. convert, window, shift (register fold: ... and fold)
+        double xs[RF ? kSlots : 1];
 #pragma unroll
         for (int c = 0; c < kSlots; ++c) {
             const int sig = NSIG == 1 ? 0 : (int)(min(u0 + c / kSlotsPerUnit, nUnits - 1) % NSIG);
@@ -267,8 +308,14 @@ __global__ __launch_bounds__(kWave * kMdctWaves, 2) void mdct_wave_kernel(
                 v = sig == 2 ? (l + r) / 2.0 : (l - r) / 2.0;
             }
             const double x = v * wv[c];
+            if (RF) { xs[RF ? c : 0] = x; continue; }
             if (SHIFT0) y[(c / kSlotsPerUnit) * N + lane + kWave * (c % kSlotsPerUnit)] = x;
             else y[dst[SHIFT0 ? 0 : c] & 0x7fffffffu] = (dst[SHIFT0 ? 0 : c] >> 31) ? -x : x;
+        }
+        if (RF) {
+#pragma unroll
+            for (int c = 0; c < kSlots; ++c)
+                if (c < fold_partner<K64>(c)) y[dst[SHIFT0 ? 0 : c]] = xs[RF ? c : 0] + xs[RF ? fold_partner<K64>(c) : 0];
         }
         if (it + 1 < run && u0 + U < nUnits) request(it + 1);          // in flight while this group is transformed
         wave_sync();
@@ -278,11 +325,15 @@ __global__ __launch_bounds__(kWave * kMdctWaves, 2) void mdct_wave_kernel(
             const int g = lane + kWave * c;
             if ((c + 1) * kWave <= U * Q || g < U * Q) {
                 const int ug = g / Q, n = g % Q;
+                if (RF) {
+                    A[g] = cmul(make_double2(y[2 * n], y[M - 1 - 2 * n]), preL[n]);
+                    continue;
+                }
                 const double* yu = y + ug * N;
                 const int j0 = 2 * n, j1 = M - 1 - 2 * n, h = Q;
                 const double u0v = (j0 < h) ? (-yu[3 * h - 1 - j0] - yu[3 * h + j0]) : (yu[j0 - h] - yu[3 * h - 1 - j0]);
                 const double u1v = (j1 < h) ? (-yu[3 * h - 1 - j1] - yu[3 * h + j1]) : (yu[j1 - h] - yu[3 * h - 1 - j1]);
-                A[g] = cmul(make_double2(u0v, u1v), preR[c]);
+                A[g] = cmul(make_double2(u0v, u1v), preR[RF ? 0 : c]);
             }
         }
         wave_sync();
@@ -295,7 +346,7 @@ __global__ __launch_bounds__(kWave * kMdctWaves, 2) void mdct_wave_kernel(
             const int g = lane + kWave * c;
             if ((c + 1) * kWave <= U * Q || g < U * Q) {
                 const int ug = g / Q, k = g % Q;
-                const double2 cc = cmul(T[g], postR[c]);
+                const double2 cc = cmul(T[g], RF ? postL[k] : postR[RF ? 0 : c]);
                 double* xu = stage + ug * M;
                 xu[2 * k] = S.twoOverN * cc.x;
                 xu[M - 1 - 2 * k] = S.twoOverN * (-cc.y);
@@ -594,6 +645,22 @@ __global__ __launch_bounds__(kWave * kMsWaves) void ms_switch_direct_kernel(int6
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
+// workgroups of an mdct_wave_kernel instantiation that the current device holds at once (occupancy x compute units), asked
+// of the runtime once per instantiation
+static int mdct_wave_slots(const void* kernel, size_t lds) {
+    static std::mutex mu;
+    static std::map<const void*, int> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = cache.find(kernel);
+    if (it != cache.end()) return it->second;
+    int perCu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, kWave * kMdctWaves, lds) != hipSuccess || perCu < 1) perCu = 2;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus < 1)
+        cus = 256;
+    return cache[kernel] = perCu * cus;
+}
+
 hipError_t launch_mdct(const DevShape& S, int64_t nFrames, const void* chL, const void* chR, int fmt, int64_t stride,
                        const int64_t* offsets, bool applyWindow, double* lines, int* oscale, hipStream_t st) {
     if (nFrames <= 0) return hipSuccess;
@@ -601,22 +668,34 @@ hipError_t launch_mdct(const DevShape& S, int64_t nFrames, const void* chL, cons
         return launch_mdct_long(S, nFrames, chL, chR, fmt, stride, offsets, lines, oscale, st);
     const int nsig = chR ? 4 : 1;
     // the other shapes of the reference's block switching (short 128 + 128: four units per wavefront at a time; transitions
-    // 1024 + 128 and 128 + 1024: one), windowed: mdct_wave_kernel.  The run length trades the once-per-workgroup constants
-    // against the number of workgroups.
+    // 1024 + 128 and 128 + 1024: one), windowed: mdct_wave_kernel.  Its wavefronts walk runs of up to kMdctMaxRun groups; the
+    // number of wavefronts is a whole multiple of what the chip holds at once (mdct_wave_slots), so that a launch of one to
+    // three rounds of workgroups -- the block-switched step's sizes -- has no thin last round.
     if (applyWindow && !(reinterpret_cast<uintptr_t>(lines) & 15) && ((S.N == 256 && S.shift == 0) || S.N == 1152)) {
         const int64_t nUnits = nFrames * nsig;
         const int U = S.N == 256 ? 4 : 1;
         const int64_t groups = (nUnits + U - 1) / U;
-        const int run = (int)std::min<int64_t>(kMdctMaxRun, std::max<int64_t>(1, groups / (kMdctWaves * 1024)));
-        const unsigned grid = (unsigned)((groups + (int64_t)kMdctWaves * run - 1) / ((int64_t)kMdctWaves * run));
-        const size_t ldsW = (size_t)(kMdctWaves * (U * S.N + 2 * U * S.Q) + 2 * S.Q) * sizeof(double);
-#define MRC_MDCT_WAVE(TY, NN, UU, NS)                                                                                  \
-    hipLaunchKernelGGL((mdct_wave_kernel<TY, NN, UU, NS, NN == 256>), dim3(grid), dim3(kWave * kMdctWaves), ldsW, st, S, nUnits, run, \
-                       (const TY*)chL, (const TY*)chR, stride, offsets, lines, oscale)
+        // transition blocks fold in registers (shift -+224: chunk pairing 15 / 1)
+        const int k64 = S.N == 1152 ? (S.shift == -224 ? 15 : S.shift == 224 ? 1 : -1) : 0;
+        if (k64 < 0) return hipErrorInvalidValue;       // (N = 1152 comes from 1024 + 128 or 128 + 1024 only)
+        const size_t ldsW = (size_t)(kMdctWaves * (k64 ? S.N : U * S.N + 2 * U * S.Q) + (k64 ? 6 : 2) * S.Q) * sizeof(double);
+        int64_t nWaves = 0;
+        unsigned grid = 0;
+        auto size_launch = [&](const void* kernel) {
+            const int64_t perRound = (int64_t)mdct_wave_slots(kernel, ldsW) * kMdctWaves;   // wavefronts resident at once
+            if (groups <= perRound) nWaves = groups;                                       // one group per wavefront
+            else nWaves = (groups + perRound * kMdctMaxRun - 1) / (perRound * kMdctMaxRun) * perRound;
+            grid = (unsigned)((nWaves + kMdctWaves - 1) / kMdctWaves);
+        };
+#define MRC_MDCT_WAVE(TY, NN, UU, NS, KK)                                                                              \
+    size_launch(reinterpret_cast<const void*>(&mdct_wave_kernel<TY, NN, UU, NS, NN == 256, KK>));                      \
+    hipLaunchKernelGGL((mdct_wave_kernel<TY, NN, UU, NS, NN == 256, KK>), dim3(grid), dim3(kWave * kMdctWaves), ldsW, st, S, nUnits, \
+                       nWaves, (const TY*)chL, (const TY*)chR, stride, offsets, lines, oscale)
 #define MRC_MDCT_WAVE_T(TY)                                                                                            \
     do {                                                                                                               \
-        if (S.N == 256) { if (nsig == 1) MRC_MDCT_WAVE(TY, 256, 4, 1); else MRC_MDCT_WAVE(TY, 256, 4, 4); }            \
-        else { if (nsig == 1) MRC_MDCT_WAVE(TY, 1152, 1, 1); else MRC_MDCT_WAVE(TY, 1152, 1, 4); }                     \
+        if (S.N == 256) { if (nsig == 1) { MRC_MDCT_WAVE(TY, 256, 4, 1, 0); } else { MRC_MDCT_WAVE(TY, 256, 4, 4, 0); } } \
+        else if (k64 == 15) { if (nsig == 1) { MRC_MDCT_WAVE(TY, 1152, 1, 1, 15); } else { MRC_MDCT_WAVE(TY, 1152, 1, 4, 15); } } \
+        else { if (nsig == 1) { MRC_MDCT_WAVE(TY, 1152, 1, 1, 1); } else { MRC_MDCT_WAVE(TY, 1152, 1, 4, 1); } }       \
     } while (0)
         if (fmt == kSampleI16) MRC_MDCT_WAVE_T(short); else MRC_MDCT_WAVE_T(double);
 #undef MRC_MDCT_WAVE_T
