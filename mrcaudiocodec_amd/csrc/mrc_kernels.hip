@@ -185,7 +185,7 @@ __device__ __forceinline__ double wave_max4(double p0, double p1, double p2, dou
 }
 
 constexpr int kMdctWaves = 4;                           // waves per workgroup, each with its own groups of units
-constexpr int kMdctMaxRun = 8;                          // groups per wave, at most
+constexpr int kMdctMaxRun = 16;                         // groups per wave, at most
 // K64 != 0 (transition blocks, N = 1152, shift = -+224): the fold N -> N/2 happens in REGISTERS.  The two samples that fold
 // into one DCT-IV input are n and (64 K64 + 63 - n) mod N (K64 = 15 for 1024 + 128, 1 for 128 + 1024), i.e. chunk c of 64
 // samples pairs with chunk (K64 - c) mod 18 read backwards: the second chunk of every pair is loaded with the lane order
@@ -215,6 +215,34 @@ __global__ __launch_bounds__(kWave * kMdctWaves, K64 ? 3 : 2) void mdct_wave_ker
     double2* B = reinterpret_cast<double2*>(y);
     double2* wl = reinterpret_cast<double2*>(smem + kMdctWaves * kWaveLds);          // [Q] e^{-2 pi i t/Q}
     __shared__ long long sOff[kMdctWaves][kMdctMaxRun * U];                          // sample offset of every unit of a wave's run
+    // the groups are dealt to the launch's nWaves wavefronts in contiguous runs that differ by at most one group (the host
+    // sizes nWaves so that the workgroups fill the chip a whole number of times and no run exceeds kMdctMaxRun)
+    const int64_t nGroups = (nUnits + U - 1) / U;
+    const int64_t waveId = (int64_t)blockIdx.x * kMdctWaves + wave;
+    const int64_t firstGroup = waveId < nWaves ? waveId * nGroups / nWaves : 0;
+    const int run = waveId < nWaves ? (int)((waveId + 1) * nGroups / nWaves - firstGroup) : 0;   // (0: a wave beyond the last)
+    // the sample offsets of all units of this wave's run, fetched at once (a scalar load per group inside the loop would put
+    // a memory round trip in front of every group's sample loads)
+    if (lane < run * U) {
+        const int64_t unit = min(firstGroup * U + lane, nUnits - 1);                 // (the tail repeats the last unit)
+        const int64_t f = NSIG == 1 ? unit : unit / NSIG;
+        sOff[wave][lane] = offsets ? offsets[f] : f * stride;
+    }
+    wave_sync();
+    // raw samples of the group in flight: requested one group ahead, converted when their group starts.  Coalesced: 64
+    // consecutive samples of one unit per load; a joint group needs both channels (its units are consecutive signals of the
+    // same frames).
+    SampleT rawL[kSlots], rawR[NSIG == 1 ? 1 : kSlots];
+    auto request = [&](int it) {
+#pragma unroll
+        for (int c = 0; c < kSlots; ++c) {
+            const int ln = (RF && c > fold_partner<K64>(c)) ? kWave - 1 - lane : lane;
+            const int64_t i = sOff[wave][it * U + c / kSlotsPerUnit] + ln + kWave * (c % kSlotsPerUnit);
+            rawL[c] = chL[i];
+            if (NSIG != 1) rawR[c] = chR[i];
+        }
+    };
+    if (run > 0) request(0);                            // in flight while the constants below are fetched
     double2* preL = wl + Q;                             // register fold: pre- / post-twiddles in LDS too ([Q] each): the 40
     double2* postL = preL + Q;                          // registers they would take are what keeps three waves on a SIMD
     for (int t = threadIdx.x; t < Q; t += kWave * kMdctWaves) {
@@ -262,36 +290,7 @@ __global__ __launch_bounds__(kWave * kMdctWaves, K64 ? 3 : 2) void mdct_wave_ker
         postR[c] = S.post[n];
     }
     __syncthreads();                                    // twiddle table visible to all waves
-
-    // the groups are dealt to the launch's nWaves wavefronts in contiguous runs that differ by at most one group (the host
-    // sizes nWaves so that the workgroups fill the chip a whole number of times and no run exceeds kMdctMaxRun)
-    const int64_t nGroups = (nUnits + U - 1) / U;
-    const int64_t waveId = (int64_t)blockIdx.x * kMdctWaves + wave;
-    if (waveId >= nWaves) return;                       // wave-uniform, after the workgroup's only barrier
-    const int64_t firstGroup = waveId * nGroups / nWaves;
-    const int run = (int)((waveId + 1) * nGroups / nWaves - firstGroup);
-    // the sample offsets of all units of this wave's run, fetched at once (a scalar load per group inside the loop would put
-    // a memory round trip in front of every group's sample loads)
-    if (lane < run * U) {
-        const int64_t unit = min(firstGroup * U + lane, nUnits - 1);                 // (the tail repeats the last unit)
-        const int64_t f = NSIG == 1 ? unit : unit / NSIG;
-        sOff[wave][lane] = offsets ? offsets[f] : f * stride;
-    }
-    wave_sync();
-    // raw samples of the group in flight: requested one group ahead, converted when their group starts.  Coalesced: 64
-    // consecutive samples of one unit per load; a joint group needs both channels (its units are consecutive signals of the
-    // same frames).
-    SampleT rawL[kSlots], rawR[NSIG == 1 ? 1 : kSlots];
-    auto request = [&](int it) {
-#pragma unroll
-        for (int c = 0; c < kSlots; ++c) {
-            const int ln = (RF && c > fold_partner<K64>(c)) ? kWave - 1 - lane : lane;
-            const int64_t i = sOff[wave][it * U + c / kSlotsPerUnit] + ln + kWave * (c % kSlotsPerUnit);
-            rawL[c] = chL[i];
-            if (NSIG != 1) rawR[c] = chR[i];
-        }
-    };
-    if (run > 0) request(0);
+    if (run == 0) return;                               // wave-uniform, after the workgroup's only barrier
     for (int it = 0; it < run; ++it) {
         const int64_t u0 = (firstGroup + it) * U;
         if (u0 >= nUnits) break;                        // wave-uniform
@@ -645,20 +644,24 @@ __global__ __launch_bounds__(kWave * kMsWaves) void ms_switch_direct_kernel(int6
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-// workgroups of an mdct_wave_kernel instantiation that the current device holds at once (occupancy x compute units), asked
-// of the runtime once per instantiation
-static int mdct_wave_slots(const void* kernel, size_t lds) {
+// workgroups of mdct_wave_kernel that the current device holds at once: what the LDS of a CU (160 KiB) admits, at most the
+// three waves per SIMD its instantiations' registers allow (launch bounds / the compiler's report), times the compute units
+static int mdct_wave_slots(size_t lds) {
     static std::mutex mu;
-    static std::map<const void*, int> cache;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = cache.find(kernel);
-    if (it != cache.end()) return it->second;
-    int perCu = 0, dev = 0, cus = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, kWave * kMdctWaves, lds) != hipSuccess || perCu < 1) perCu = 2;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        cus < 1)
-        cus = 256;
-    return cache[kernel] = perCu * cus;
+    static std::map<int, int> cusOf;                    // device -> compute units
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = cusOf.find(dev);
+        if (it != cusOf.end()) cus = it->second;
+        else {
+            if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+            cusOf[dev] = cus;
+        }
+    }
+    const size_t perWg = lds + sizeof(long long) * kMdctWaves * kMdctMaxRun * 4 + 256;   // (+ the static part, rounded up)
+    return (int)std::min<size_t>(3, std::max<size_t>(1, (160u << 10) / perWg)) * cus;
 }
 
 hipError_t launch_mdct(const DevShape& S, int64_t nFrames, const void* chL, const void* chR, int fmt, int64_t stride,
@@ -681,14 +684,14 @@ hipError_t launch_mdct(const DevShape& S, int64_t nFrames, const void* chL, cons
         const size_t ldsW = (size_t)(kMdctWaves * (k64 ? S.N : U * S.N + 2 * U * S.Q) + (k64 ? 6 : 2) * S.Q) * sizeof(double);
         int64_t nWaves = 0;
         unsigned grid = 0;
-        auto size_launch = [&](const void* kernel) {
-            const int64_t perRound = (int64_t)mdct_wave_slots(kernel, ldsW) * kMdctWaves;   // wavefronts resident at once
+        auto size_launch = [&]() {
+            const int64_t perRound = (int64_t)mdct_wave_slots(ldsW) * kMdctWaves;            // wavefronts resident at once
             if (groups <= perRound) nWaves = groups;                                       // one group per wavefront
             else nWaves = (groups + perRound * kMdctMaxRun - 1) / (perRound * kMdctMaxRun) * perRound;
             grid = (unsigned)((nWaves + kMdctWaves - 1) / kMdctWaves);
         };
 #define MRC_MDCT_WAVE(TY, NN, UU, NS, KK)                                                                              \
-    size_launch(reinterpret_cast<const void*>(&mdct_wave_kernel<TY, NN, UU, NS, NN == 256, KK>));                      \
+    size_launch();                                                                                                     \
     hipLaunchKernelGGL((mdct_wave_kernel<TY, NN, UU, NS, NN == 256, KK>), dim3(grid), dim3(kWave * kMdctWaves), ldsW, st, S, nUnits, \
                        nWaves, (const TY*)chL, (const TY*)chR, stride, offsets, lines, oscale)
 #define MRC_MDCT_WAVE_T(TY)                                                                                            \
