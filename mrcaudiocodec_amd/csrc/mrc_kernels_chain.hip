@@ -57,6 +57,33 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     const uint2v r32 = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
     return (int)(r32.x + r32.y);
 }
+// Four per-lane partial sums -> every lane of row r (lanes 16 r .. 16 r + 15) ends with the wave-wide sum of value r: two
+// rounds of permlane swaps fold the four registers into one whose rows belong to the four values, then one reduction inside
+// the rows (10 instead of 32 instructions for four separate sums)
+__device__ __forceinline__ unsigned wave_sum4_u(unsigned a, unsigned b, unsigned c, unsigned d) {
+    uint2v t = __builtin_amdgcn_permlane32_swap(a, c, false, false);    // x = {a lower half, c lower half}, y = the upper halves
+    const unsigned ac = t.x + t.y;                                      // lanes 0-31: a over both halves; lanes 32-63: c
+    t = __builtin_amdgcn_permlane32_swap(b, d, false, false);
+    const unsigned bd = t.x + t.y;
+    t = __builtin_amdgcn_permlane16_swap(ac, bd, false, false);         // x = {ac row 0, bd row 0, ac row 2, bd row 2}, y = the odd rows
+    int q = (int)(t.x + t.y);                                           // row r: value r
+    q += __builtin_amdgcn_update_dpp(0, q, 0xB1, 0xf, 0xf, false);
+    q += __builtin_amdgcn_update_dpp(0, q, 0x4E, 0xf, 0xf, false);
+    q += __builtin_amdgcn_update_dpp(0, q, 0x141, 0xf, 0xf, false);
+    q += __builtin_amdgcn_update_dpp(0, q, 0x128, 0xf, 0xf, false);
+    return (unsigned)q;
+}
+// ... two values: lanes 0-31 end with the sum of a, lanes 32-63 with the sum of b
+__device__ __forceinline__ int wave_sum2_i(int a, int b) {
+    uint2v t = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+    int q = (int)(t.x + t.y);
+    q += __builtin_amdgcn_update_dpp(0, q, 0xB1, 0xf, 0xf, false);
+    q += __builtin_amdgcn_update_dpp(0, q, 0x4E, 0xf, 0xf, false);
+    q += __builtin_amdgcn_update_dpp(0, q, 0x141, 0xf, 0xf, false);
+    q += __builtin_amdgcn_update_dpp(0, q, 0x128, 0xf, 0xf, false);
+    t = __builtin_amdgcn_permlane16_swap((unsigned)q, (unsigned)q, false, false);
+    return (int)(t.x + t.y);
+}
 __device__ __forceinline__ int wave_max_i(int v) {
     v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));
     v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));
@@ -334,6 +361,12 @@ __device__ __forceinline__ SwitchRegs switch_load(const LoadView& G, int64_t idx
     if (tid < G.nsig) W.osc = G.oscale[idx * G.nsig + tid];
     return W;
 }
+// the overall scale of signal sg, from the lanes q < 4 of the wave that hold the four scales (whole wave active)
+__device__ __forceinline__ int osc_of(int osc, int sg) {
+    const int o0 = __builtin_amdgcn_readlane(osc, 0), o1 = __builtin_amdgcn_readlane(osc, 1);
+    const int o2 = __builtin_amdgcn_readlane(osc, 2), o3 = __builtin_amdgcn_readlane(osc, 3);
+    return sg == 0 ? o0 : sg == 1 ? o1 : sg == 2 ? o2 : o3;
+}
 // ms_stereo.py:70-81: stream 0 carries Mid-or-Left, stream 1 Side-or-Right per band
 __device__ __forceinline__ int signal_of(const LoadView& G, int tid, int msRaw) {
     return G.joint ? (msRaw ? 2 : 0) + (tid >= G.nb ? 1 : 0) : 0;
@@ -422,15 +455,14 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
     __shared__ int sBits[kWave];                         // bits granted per (stream, band) while the tail is walked
     __shared__ unsigned sEv[kMaxEvents + kChainThreads];
     __shared__ unsigned sPre[kMaxEvents + kChainThreads];
-    __shared__ double sPeak[kWave];                      // raw max |X| of the (stream, band)'s signal
     __shared__ int sSig[2][kWave];                       // signal of (stream, band) i: this item's / the next item's (by parity)
     __shared__ int sOsc[2][4];                           // overall scale of signal q, likewise
     __shared__ unsigned sInfo[kWave];                    // per (stream, band): bits | scale factor << 8
     __shared__ unsigned sEsc[kWave];                     // per (stream, band): bits + escape code length of each table, 8 bits each
     __shared__ unsigned sLut[kLutSize + 1];              // per value: the four code lengths, 8 bits each (0: not in the table)
-    __shared__ int sCtl[4];                              // remaining bits, raw bits of stream 0 / 1, reservoir
+    __shared__ int sCtl[4];                              // remaining bits, raw bits of stream 0 / 1
     __shared__ int sCut;                                 // events that are certain grants (counted by all waves)
-    __shared__ unsigned sAcc[4];                         // Huffman prices of the block, summed over the waves (LDS atomics)
+    __shared__ unsigned sAcc[2][4];                      // Huffman prices of the block, summed over the waves (LDS atomics); by item parity
     __shared__ int sItems[256];                          // ring of item ids (see below)
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const int64_t strmId = blockIdx.x;
@@ -442,8 +474,11 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
     }
     unsigned escLen4 = 0;                                // the escape code's length in each table
     for (int t = 0; t < 4; ++t) escLen4 |= (unsigned)kChainCodeLen[t][kChainEscape[t]] << (8 * t);
-    if (tid == 0) { sCtl[3] = reservoir[strmId]; sCut = 0; }
-    if (tid < 4) sAcc[tid] = 0u;
+    // the reservoir travels in a register of EVERY thread: each wave works the table decision out for itself from the block's
+    // price sums, so that no barrier stands between the decision and the next item's budget
+    int resReg = reservoir[strmId];
+    if (tid == 0) sCut = 0;
+    if (tid < 8) sAcc[tid >> 2][tid & 3] = 0u;
     if (tid < kWave) sBits[tid] = 0;
     const long long i0 = itemStart[strmId], i1 = itemStart[strmId + 1];
     ItemRegs<NT> R;
@@ -452,6 +487,9 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
     unsigned bandsCur[kUnitsPerThread], bandsNext[kUnitsPerThread];   // bands of the thread's lines: current / next block shape
     int nCur = 0, nNext = 0;                             // lines of the thread's (stream, band)
     int itemCur = 0, itemNext = 0, itemAfter = 0;
+    // wave 0, lane = (stream, band): the overall scale of the band's signal, this item's / the next item's -- picked from
+    // the lanes that hold the four scales when the switch arrives, so that the scale factors need no LDS round trips
+    int oscCur = 0, oscNext = 0;
     GroupView G = group_view(groups, 0);                 // the current item's group (compute side)
     LoadView Ln = load_view(groups, 0);                  // the next item's group (load side)
     int gOfG = 0, gOfLn = 0;
@@ -482,7 +520,7 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
         if (gOfG != 0) { G = group_view(groups, gOfG); Ln = load_view(groups, gOfG); }
         gOfLn = gOfG;
         const SwitchRegs W0 = switch_load(Ln, itemCur & 0x0fffffff, tid);
-        if (tid < kWave) sSig[0][tid] = signal_of(Ln, tid, W0.sig);
+        if (tid < kWave) { sSig[0][tid] = signal_of(Ln, tid, W0.sig); oscCur = osc_of(W0.osc, signal_of(Ln, tid, W0.sig)); }
         if (tid < 4) sOsc[0][tid] = W0.osc;
         unit_bands<NT>(Ln, tid, bandsCur);
         nCur = band_size(Ln);
@@ -514,7 +552,12 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
             const int p = tid + kChainThreads * j;
             sEv[p] = R.ev[j]; sPre[p] = R.pre[j];
         }
-        if (tid < kWave) { sPeak[tid] = R.peak; sSig[par ^ 1][tid] = signal_of(Ln, tid, W.sig); }
+        const double peakCur = R.peak;                   // (wave 0: raw max |X| of the lane's (stream, band))
+        if (tid < kWave) {
+            const int sgN = signal_of(Ln, tid, W.sig);
+            sSig[par ^ 1][tid] = sgN;
+            oscNext = osc_of(W.osc, sgN);
+        }
         if (tid < 4) sOsc[par ^ 1][tid] = W.osc;
         // ---- bit allocation (bitalloc.py:106-155), its HEAD by all waves, straight from the registers that hold the event
         //      list: the budget of codecThem.py:299-308 / 381-396 from the reservoir the previous item left; the events whose
@@ -522,7 +565,7 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
         //      raised to what its last such grant gives.  (nLines <= left <=> nLines + spent <= Bf; left > 0 <=> spent < Bc)
         double budget;
         {
-            const double r = (double)sCtl[3];
+            const double r = (double)resReg;
             if (G.joint) { budget = G.budgetJointPre + r; budget -= G.blkswA; budget -= G.blkswB; }
             else budget = G.budgetMono + r;
         }
@@ -552,6 +595,7 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
         MRC_CP(1);
         __syncthreads();
         MRC_CP(2);
+        if (tid < 4) sAcc[par ^ 1][tid] = 0u;            // the next item's sums (last read in the previous item's decision)
         // ---- the next item's loads go out now and land while this one is computed; and the switch of the item after it
         // (ids up to it + 3 are read here; a chunk is replaced when the scan is 8 items into the NEXT one: everything of the
         // old chunk has been read, and the new ids are visible after this iteration's barriers, 117 items before their turn)
@@ -621,12 +665,11 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
 #endif
             // ---- scale factors (codecThem.py:346-347), raw size of each stream (codecThem.py:141-146)
             const int rawMine = myBits * myN;
-            const int raw0 = wave_sum_i((valid && lane < nb) ? rawMine : 0);
-            const int raw1 = wave_sum_i((valid && lane >= nb) ? rawMine : 0);
+            const int raw01 = wave_sum2_i((valid && lane < nb) ? rawMine : 0, (valid && lane >= nb) ? rawMine : 0);
             if (valid) {
                 // codecThem.py:346-347: the scale factor comes from max |scaled line| of the band; scaling by 2^overallScale
                 // is exact, so maximum and scaling commute
-                const int sf = scale_factor32(ldexp(sPeak[lane], sOsc[par][sSig[par][lane]]), G.nScaleBits, myBits);
+                const int sf = scale_factor32(ldexp(peakCur, oscCur), G.nScaleBits, myBits);
                 sInfo[lane] = (unsigned)myBits | ((unsigned)sf << 8);
                 sEsc[lane] = escLen4 + (unsigned)myBits * 0x01010101u;
                 G.bitAlloc[idx * nTot + lane] = myBits;
@@ -634,9 +677,9 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
             }
             if (lane == 0) {
                 sCtl[0] = (int)(budget - (double)spent);                   // int(bitsLeft): truncation toward zero (bitalloc.py:155)
-                sCtl[1] = raw0;
-                sCtl[2] = raw1;
+                sCtl[1] = raw01;                                           // (lanes 0-31: stream 0)
             }
+            if (lane == 32) sCtl[2] = raw01;                               // (lanes 32-63: stream 1)
             MRC_CP(6);
         }
         __syncthreads();
@@ -687,17 +730,17 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
         }
         {
             // bytes -> 16-bit fields (per table at most 25 bits x 1024 lines): tables 0 | 2 and 1 | 3 of each stream
-            const unsigned w0 = (unsigned)wave_sum_i((int)(accA & 0x00ff00ffu)), w1 = (unsigned)wave_sum_i((int)((accA >> 8) & 0x00ff00ffu));
-            const unsigned w2 = (unsigned)wave_sum_i((int)(accB & 0x00ff00ffu)), w3 = (unsigned)wave_sum_i((int)((accB >> 8) & 0x00ff00ffu));
-            if (lane == 0) { atomicAdd(&sAcc[0], w0); atomicAdd(&sAcc[1], w1); atomicAdd(&sAcc[2], w2); atomicAdd(&sAcc[3], w3); }
+            const unsigned w = wave_sum4_u(accA & 0x00ff00ffu, (accA >> 8) & 0x00ff00ffu, accB & 0x00ff00ffu, (accB >> 8) & 0x00ff00ffu);
+            if ((lane & 15) == 0) atomicAdd(&sAcc[par][lane >> 4], w);         // row r of the wave: field pair r
         }
         MRC_CP(8);
         __syncthreads();
         MRC_CP(9);
-        if (tid == 0) {
+        {
+            // every wave for itself (uniform values); thread 0 writes the tables down
             unsigned w[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { w[q] = sAcc[q]; sAcc[q] = 0u; }
+            for (int q = 0; q < 4; ++q) w[q] = sAcc[par][q];
             int res = sCtl[0];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -711,13 +754,14 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
                         for (int t = 0; t < 4; ++t)
                             if (cost[t] < best) { best = cost[t]; table = t; }   // strictly less: raw, then the first table, win ties
                     }
-                    G.table[idx * nstream + s] = table;
+                    if (tid == 0) G.table[idx * nstream + s] = table;
                     res += raw - best;                                    // codecThem.py:202,224,274
                 }
             }
-            sCtl[3] = res;
-            if (resTrace) resTrace[it] = res;
+            resReg = res;
+            if (tid == 0 && resTrace) resTrace[it] = res;
         }
+        oscCur = oscNext;
         itemCur = itemNext;
         itemNext = itemAfter;
         itemAfter = itemAfter2;
@@ -734,10 +778,11 @@ __global__ __launch_bounds__(NT) void chain_phase_b_kernel(
             asm volatile("" : "+v"(nNext));
         }
         MRC_CP(10);
-        __syncthreads();
+        // (no barrier here: what the next item writes before its first barrier -- the event list, peaks, the other half of the
+        // signal tables, the head's counters -- was last read before this item's barrier 2 or 3; the price sums alternate)
         MRC_CP(11);
     }
-    if (tid == 0) reservoir[strmId] = sCtl[3];
+    if (tid == 0) reservoir[strmId] = resReg;
 }
 
 // Close() (pacfileThem.py:973-984): per stream and channel the last coded hop followed by a hop of zeros
@@ -792,7 +837,7 @@ hipError_t launch_chain_phase_b(int64_t nStreams, const ChainGroupDev* groups, c
     if (nStreams <= 0) return hipSuccess;
     // a workgroup per stream.  Few streams: large workgroups (the chip is idle anyway, the stream's latency is what
     // counts); many: small ones, eight streams per CU
-    if (threads <= 0) threads = nStreams <= 512 ? 512 : 256;   // (measured on one stream: 4.08 / 3.58 / 3.67 us per block at 256 / 512 / 1024)
+    if (threads <= 0) threads = nStreams <= 512 ? 512 : 256;   // (measured on one stream: 3.7 / 3.3 / 4.3 us per block at 256 / 512 / 1024)
     if (threads >= 1024)
         hipLaunchKernelGGL(chain_phase_b_kernel<1024>, dim3((unsigned)nStreams), dim3(1024), 0, st, groups, items, itemStart,
                            reservoir, resTrace, useHuffman);
