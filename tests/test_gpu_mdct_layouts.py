@@ -127,3 +127,63 @@ def test_joint_lines_of_l_and_r_equal_the_mono_lines(h):
     assert np.array_equal(Xj[:, 0], Xl[:, 0]) and np.array_equal(Xj[:, 1], Xr[:, 0])
     Xs, _ = _lines(torch, enc, dl, dl.clone(), n, HOP, None)
     assert np.array_equal(Xs[:, 2], Xl[:, 0]) and not Xs[:, 3].any()
+
+
+@pytest.mark.parametrize("ab", [(128, 128), (1024, 128), (128, 1024)])
+def test_wave_mdct_run_geometry_at_the_round_boundaries(h, ab):
+    # mdct_wave_kernel (short / transition blocks) deals its groups of units to a whole number of rounds of wavefronts in
+    # balanced runs of at most 16 groups (3 workgroups x 4 waves per CU x 256 CUs = 3072 wavefronts per round): counts on
+    # both sides of "one group per wave" (3072 groups) and of "one round of runs of 16" (49 152 groups), for the transition
+    # blocks' register-fold form and the short blocks' four-units-per-wave form.  The whole batch in one launch must equal,
+    # bit for bit, the same blocks launched in pieces of 1000 (another geometry: one group per wave), and its first and last
+    # blocks the oracle's lines; the integers of the encode ride along.
+    torch = pytest.importorskip("torch")
+    from mrcaudiocodec_amd import synth
+    from mrcaudiocodec_amd.batch import StreamEncoder
+    enc = StreamEncoder(handle=h)
+    a, b = ab
+    N, M = a + b, (a + b) // 2
+    per_group = 4 if N == 256 else 1
+    hops = 700
+    l16, r16 = _streams(torch, hops, seed=23)
+    fl = synth.pcm_to_float(l16)
+    dl, dr = torch.from_numpy(l16).to("cuda:0"), torch.from_numpy(r16).to("cuda:0")
+    span = hops * HOP - N
+
+    def run(n, lo, hi, right=None):
+        step = max(1, span // n)
+        o = torch.arange(lo, hi, device="cuda:0", dtype=torch.int64) * step + 3        # (odd sample offsets too)
+        nsig = 4 if right is not None else 1
+        lines = torch.full(((hi - lo) * nsig * M,), float("nan"), dtype=torch.float64, device="cuda:0")
+        out = enc.encode(a, b, dl, right, hi - lo, 0, o.contiguous(), lines_out=lines, fresh=True)
+        torch.cuda.synchronize()
+        return lines.cpu().numpy().reshape(hi - lo, nsig, M), {k: v.cpu().numpy() for k, v in out.items()}, step
+
+    for groups in (3071, 3072, 3073, 49152, 49153):
+        n = groups * per_group - (1 if groups % 2 else 0) * (per_group - 1)            # (odd counts end inside a group)
+        X, ints, step = run(n, 0, n)
+        assert not np.isnan(X).any()
+        ends = list(range(4)) + list(range(n - 4, n))
+        bl = np.stack([fl[i * step + 3:i * step + 3 + N] for i in ends])
+        ref = fast.mdct_batch(bl, a, b)
+        assert np.abs(X[ends, 0] - ref).max() <= MDCT_RTOL * np.abs(ref).max()
+        for lo in range(0, n, 1000 * per_group):
+            hi = min(n, lo + 1000 * per_group)
+            # the piece uses the whole batch's step, so that its blocks are the same samples
+            o = torch.arange(lo, hi, device="cuda:0", dtype=torch.int64) * step + 3
+            lines = torch.full(((hi - lo) * M,), float("nan"), dtype=torch.float64, device="cuda:0")
+            part = enc.encode(a, b, dl, None, hi - lo, 0, o.contiguous(), lines_out=lines, fresh=True)
+            torch.cuda.synchronize()
+            assert np.array_equal(lines.cpu().numpy().reshape(hi - lo, M), X[lo:hi, 0]), (groups, lo)
+            for k in part:
+                assert np.array_equal(part[k].cpu().numpy(), ints[k][lo:hi]), (groups, lo, k)
+    # joint: units = 4 x blocks (L, R, M, S of a block are consecutive units of consecutive groups)
+    fr = synth.pcm_to_float(r16)
+    for nj in (769, 12289):
+        Xj, _, step = run(nj, 0, nj, right=dr)
+        assert not np.isnan(Xj).any()
+        for i in (0, 1, nj // 2, nj - 1):
+            bl, br = fl[i * step + 3:i * step + 3 + N][None], fr[i * step + 3:i * step + 3 + N][None]
+            for q, x in enumerate((bl, br, (bl + br) / 2.0, (bl - br) / 2.0)):
+                ref = fast.mdct_batch(x, a, b)
+                assert np.abs(Xj[i, q] - ref[0]).max() <= MDCT_RTOL * max(np.abs(ref).max(), 1e-300), (nj, i, q)
