@@ -43,10 +43,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--streams", type=int, default=16)
     ap.add_argument("--hops", type=int, default=48)
+    ap.add_argument("--seed", type=int, default=1000, help="seed of the first stream (stream s takes seed + s)")
     a = ap.parse_args()
     h = Handle()
     t0 = time.time()
-    streams = np.stack([make_stream(a.hops, 1000 + s) for s in range(a.streams)])
+    streams = np.stack([make_stream(a.hops, a.seed + s) for s in range(a.streams)])
     shapes = [transient.block_shapes(h, streams[s]) for s in range(a.streams)]
     got = pacfile.encode_stereo_streams(h, streams, shapes, use_huffman=True)
     bad_shapes = bad_bytes = bad_dec = 0
@@ -71,8 +72,9 @@ def main():
         print("stream %d/%d: %d blocks (%d not long), %d bytes, %.0f s" %
               (s + 1, a.streams, len(want_shapes), sum(1 for (_, x, y) in want_shapes if (x, y) != (1024, 1024)),
                len(want), time.time() - t0), flush=True)
-    print("RESULT pac sweep: streams=%d blocks=%d (not long: %d) shape_mismatches=%d byte_mismatches=%d "
-          "decode_mismatches=%d max_rel_decode_err=%.3g" % (a.streams, n_blocks, n_short, bad_shapes, bad_bytes, bad_dec, worst),
+    print("RESULT pac sweep: streams=%d hops=%d seed=%d blocks=%d (not long: %d) shape_mismatches=%d byte_mismatches=%d "
+          "decode_mismatches=%d max_rel_decode_err=%.3g" % (a.streams, a.hops, a.seed, n_blocks, n_short, bad_shapes, bad_bytes,
+                                                             bad_dec, worst),
           flush=True)
     h.close()
 
