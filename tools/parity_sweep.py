@@ -46,8 +46,13 @@ def main():
     ap.add_argument("--shapes", type=int, default=0, help="blocks per short / transition shape (mono, and a quarter joint)")
     ap.add_argument("--chunk", type=int, default=1024)
     ap.add_argument("--seed-offset", type=int, default=0, help="added to every generator seed: a sweep over OTHER frames than the default's")
+    ap.add_argument("--exact-spread", action="store_true",
+                    help="MRC_OPT_EXACT_SPREAD: the spreading function operation by operation in masker order (psychoac.py:68-78)")
     args = ap.parse_args()
     h = Handle()
+    if args.exact_spread:
+        h.set_option(1, 1)
+        print("# MRC_OPT_EXACT_SPREAD = %d" % h.get_option(1), flush=True)
     t0 = time.time()
     for (a, b) in ((128, 128), (1024, 128), (128, 1024)) if args.shapes else ():
         for joint, n in ((False, args.shapes), (True, args.shapes // 4)):
